@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the yolo-fastest-1.1 forward path on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path (first conv ... YOLO decode + NMS)
+over one batch of 64 synthetic 320x320x3 frames PER GPU, inputs resident in HBM,
+ending with the NMS'd boxes of every frame of the job in host memory on rank 0
+(RCCL gather of the fixed-size per-frame detection records for N > 1).  Weak
+scaling: the global batch is 64*N.  Weights are broadcast from rank 0 over RCCL
+once, before the timed region.
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement"):
+  value        whole-job frames/s
+  roofline     the depthwise 3x3 kernel on BASELINE config[1] (320x320x64, batch 64):
+               algorithmic bytes / mean launch time measured with HIP events on
+               the launch stream, against the 8 TB/s HBM3E peak
+  cpu_baseline the reference conv-v6.c path (oracle/_ref, built with the
+               reference's own flags) timed on this box's host cores, N=1 only
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FRAMES_PER_GPU = int(os.environ.get("FFCNN_BENCH_FRAMES_PER_GPU", "64"))
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_MFMA_PEAK_TF = 157.3
+
+
+class DevBuf:
+    """zero-copy torch view of a raw device pointer via __cuda_array_interface__"""
+
+    def __init__(self, ptr, nbytes, typestr="|u1"):
+        item = int(typestr[2:])
+        self.__cuda_array_interface__ = {"shape": (nbytes // item,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def dev_tensor(torch, ptr, nbytes, typestr="|u1"):
+    return torch.as_tensor(DevBuf(ptr, nbytes, typestr), device="cuda")
+
+
+def cpu_flags():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return set()
+
+
+def pick_ref_lib():
+    """oracle/_ref build of the unmodified reference (conv-v6.c, reference flags) that this host can run."""
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    have = cpu_flags()
+    cands = []
+    nat = os.path.join(ref, "native.cpuflags")
+    if os.path.exists(nat) and set(open(nat).read().split()) <= have:
+        cands.append(("v6_fast_native", "-Ofast -march=native (build host ISA)"))
+    if {"avx2", "fma", "bmi2"} <= have:
+        cands.append(("v6_fast_v3", "-Ofast -march=x86-64-v3"))
+    cands.append(("v6_fast_sse2", "-Ofast -msse2"))
+    for name, desc in cands:
+        p = os.path.join(ref, "libffcnn_ref_%s.so" % name)
+        if os.path.exists(p):
+            return name, desc
+    return None, None
+
+
+CPU_WORKER = r"""
+import sys, time
+sys.path.insert(0, %(root)r)
+from oracle import orc
+bgr, w, h = orc.load_bmp()
+r = orc.Ref(%(variant)r)
+for _ in range(3):
+    r.set_input_image(bgr, w, h); r.forward()
+n, t0 = 0, time.perf_counter()
+while time.perf_counter() - t0 < %(secs)f:
+    r.set_input_image(bgr, w, h); r.forward(); n += 1
+dt = time.perf_counter() - t0
+print(n, dt, r.n.bbox_num)
+"""
+
+
+def cpu_baseline(secs=8.0):
+    """Reference CPU path on this box's host cores: 1 thread, then one process per core."""
+    variant, desc = pick_ref_lib()
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    if variant is None:
+        # no reference build travelled: time the oracle port instead (slower, scalar)
+        from oracle import orc
+        bgr, w, h = orc.load_bmp()
+        o = orc.Oracle()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < secs:
+            o.set_input_image(bgr, w, h)
+            o.forward(1)
+            n += 1
+        dt = time.perf_counter() - t0
+        o.close()
+        return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d frames of test.bmp at 320x320 through oracle/ffcnn_oracle.c (-O2), 1 thread, %.1f s" % (n, dt)}
+
+    def run(nproc):
+        code = CPU_WORKER % dict(root=ROOT, variant=variant, secs=secs)
+        procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True) for _ in range(nproc)]
+        tot = 0.0
+        frames = 0
+        for p in procs:
+            out = p.communicate()[0].split()
+            if p.returncode == 0 and len(out) >= 2:
+                tot += int(out[0]) / float(out[1])
+                frames += int(out[0])
+        return tot, frames
+
+    one, f1 = run(1)
+    allc, fa = run(ncpu) if ncpu > 1 else (one, f1)
+    model = ""
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except (OSError, IndexError):
+        pass
+    return {"value": round(one, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+            "sample": "%d frames (~%.0f s) of net_input+net_forward on test.bmp at 320x320, reference ffcnn.c+conv-v6.c "
+                      "built %s, 1 thread" % (f1, secs, desc),
+            "all_cores": {"value": round(allc, 3), "cores": ncpu, "how": "%d independent processes, one NET each" % ncpu},
+            "cpu": model}
+
+
+def kernel_roofline(torch, capi, stream):
+    """BASELINE config[1]: depthwise 3x3 s1 p1, 64 channels x 64 frames of 320x320, leaky, BN folded."""
+    N, Cc, H, W = 64, 64, 320, 320
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.rand((Cc * N, H, W), device="cuda", generator=g) * 2 - 1          # CNHW planes
+    y = torch.empty_like(x)
+    filt = torch.zeros((Cc, 16), device="cuda")
+    filt[:, :9] = torch.rand((Cc, 9), device="cuda", generator=g) - 0.5
+    filt[:, 12] = torch.rand((Cc,), device="cuda", generator=g) + 0.5
+    filt[:, 13] = torch.rand((Cc,), device="cuda", generator=g) * 0.2 - 0.1
+    torch.cuda.synchronize()
+    us = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, Cc, Cc, 1, 1, 3, Cc, act=2,
+                                 warmup=5, iters=30, stream=stream.cuda_stream)
+    alg_bytes = 2 * N * Cc * H * W * 4
+    name = capi.kernel_name(N, W, H, Cc, Cc, 1, 1, 3, Cc)
+    gbs = alg_bytes / (us * 1e-6) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "dw3x3_traffic.json")     # per-launch HBM bytes from the PMC passes
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        except (ValueError, OSError):
+            traffic = None
+    del x, y
+    return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "us_per_launch": round(us, 2),
+            "algorithmic_bytes": alg_bytes, "workload": "dw3x3 s1 p1 320x320x64 batch 64 fp32 (BASELINE config[1])"}
+
+
+def pw_roofline(torch, capi, stream):
+    """BASELINE config[2]: pointwise 1x1 256->512 on 20x20, batch 256, leaky (MFMA-bound in fp32)."""
+    N, ic, oc, H, W = 256, 256, 512, 20, 20
+    g = torch.Generator(device="cuda").manual_seed(1235)
+    x = torch.rand((ic * N, H, W), device="cuda", generator=g) * 2 - 1
+    y = torch.empty((oc * N, H, W), device="cuda")
+    filt = torch.zeros((oc, ic + 4), device="cuda")
+    filt[:, :ic] = torch.rand((oc, ic), device="cuda", generator=g) - 0.5
+    filt[:, ic] = torch.rand((oc,), device="cuda", generator=g) + 0.5
+    filt[:, ic + 1] = torch.rand((oc,), device="cuda", generator=g) * 0.2 - 0.1
+    torch.cuda.synchronize()
+    us = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2,
+                                 warmup=3, iters=20, stream=stream.cuda_stream)
+    flops = 2.0 * oc * ic * N * H * W
+    tfs = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc), "achieved": round(tfs, 2),
+            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tfs / FP32_MFMA_PEAK_TF, 4),
+            "us_per_launch": round(us, 2), "dtype": "f32",
+            "workload": "pw1x1 256->512 20x20 batch 256 fp32 (BASELINE config[2])"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ffcnn_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    capi.lib().ffgpu_set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    B = FRAMES_PER_GPU
+    stream = torch.cuda.Stream()
+    net = capi.Net()
+    # weights: rank 0's folded filter rows -> every GPU over RCCL (one-off, outside the timed region)
+    wptr, wbytes = net.weights_dev()
+    if world > 1:
+        wt = dev_tensor(torch, wptr, wbytes, "<f4")
+        if rank != 0:
+            wt.zero_()
+        dist.broadcast(wt, src=0)
+        torch.cuda.synchronize()
+        net.weights_commit()
+    ex = net.executor(B)
+
+    # synthetic frames (seeded per rank); frame 0 of rank 0 is the letterboxed test.bmp so boxes can be checked
+    g = torch.Generator(device="cuda").manual_seed(1236 + rank)
+    x = torch.rand((B, 3, 320, 320), device="cuda", generator=g)
+    check = None
+    if rank == 0:
+        # frame 0 = data/test.bmp through the library's own net_input; expected boxes are the
+        # reference's (tests/golden/boxes.json, produced by the unmodified reference build)
+        try:
+            bgr, w, h = capi.load_bmp(os.path.join(ROOT, "data", "test.bmp"))
+            net.set_input_image(bgr, w, h)
+            x[0] = torch.from_numpy(net.input.copy()).cuda()
+            check = json.load(open(os.path.join(ROOT, "tests", "golden", "boxes.json")))["net_320x320_v0"]["boxes"]
+        except Exception as e:
+            print("bench: golden check unavailable: %r" % (e,), file=sys.stderr)
+    ex.set_scale(640, 320)      # every frame is treated as a 640-wide source letterboxed to 320 (test.bmp's ratio)
+
+    dptr, dbytes = ex.dets_dev()
+    dets = dev_tensor(torch, dptr, dbytes)                      # this rank's records (uint8 view)
+    gathered = [torch.empty_like(dets) for _ in range(world)] if (world > 1 and rank == 0) else None
+    host = torch.empty((world, dbytes), dtype=torch.uint8).pin_memory() if rank == 0 else None
+
+    def step():
+        ex.forward_dev(x.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.gather(dets, gathered, dst=0)
+            if rank == 0:
+                for r in range(world):
+                    host[r].copy_(gathered[r], non_blocking=True)
+        else:
+            host[0].copy_(dets, non_blocking=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        fps = B * world * args.steps / dt
+        ok = None
+        if check is not None:
+            rec = np.frombuffer(host[0].numpy().tobytes(), capi.DETS_DTYPE, B)
+            got = rec[0]["box"][: rec[0]["count"]]
+            ok = bool(len(got) == len(check) and all(
+                int(a["type"]) == int(b["type"]) and abs(float(a["score"]) - float(b["score"])) < 1e-4 and
+                max(abs(float(a[k]) - float(b[k])) for k in ("x1", "y1", "x2", "y2")) < 0.05 for a, b in zip(got, check)))
+        out = {
+            "metric": "frames/sec yolo-fastest-1.1 @320x320 batch-64 per GPU (full forward: conv stack + YOLO decode + NMS, boxes on rank 0)",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[3]/[4])",
+                       "frames_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "launches_per_step": ex.kernel_count, "arena_MB": round(ex.arena_bytes / 2**20, 1),
+                       "weights": "data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL, untimed)",
+                       "boxes_match_reference_golden_frame0": ok},
+        }
+        if world == 1 and not args.no_kernel_roofline:
+            out["roofline"] = kernel_roofline(torch, capi, stream)
+            out["roofline_pw"] = pw_roofline(torch, capi, stream)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["gpu_vs_cpu_1thread"] = round(fps / out["cpu_baseline"]["value"], 1) if out["cpu_baseline"]["value"] else None
+        print(json.dumps(out))
+    ex.close()
+    net.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,358 @@
+"""ctypes mirror of include/ffcnn.h, include/conv.h and include/ffcnn_hip.h."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+DATA = os.path.join(ROOT, "data")
+CFG = os.path.join(DATA, "yolo-fastest-1.1.cfg")
+WEIGHTS = os.path.join(DATA, "yolo-fastest-1.1.weights")
+
+f32p = C.POINTER(C.c_float)
+
+
+class FFGPU:
+    MAX_DET = 128
+    MAX_CAND = 1024
+    KEEP_ALL, COMPAT_V6, NO_GRAPH, NO_FUSE = 1, 2, 4, 8
+    K_AUTO, K_GENERIC, K_DW_STREAM, K_DW_LDS, K_PW_MFMA, K_PW_GEMM, K_PW_VALU = range(7)
+
+
+class LAYER(C.Structure):            # include/ffcnn.h (120 bytes)
+    _fields_ = [("type", C.c_int), ("refcnt", C.c_int), ("data", f32p), ("filter", f32p),
+                ("w", C.c_int), ("h", C.c_int), ("c", C.c_int), ("pad", C.c_int), ("stride", C.c_int),
+                ("fn", C.c_int), ("fs", C.c_int), ("groups", C.c_int),
+                ("batchnorm", C.c_int), ("activation", C.c_int),
+                ("depend_list", C.c_int * 4), ("depend_num", C.c_int),
+                ("class_num", C.c_int), ("anchor_list", (C.c_int * 2) * 3),
+                ("ignore_thres", C.c_float), ("scale_x_y", C.c_float)]
+
+
+class BBOX(C.Structure):             # 24 bytes
+    _fields_ = [("type", C.c_int), ("score", C.c_float), ("x1", C.c_float), ("y1", C.c_float),
+                ("x2", C.c_float), ("y2", C.c_float)]
+
+
+class NET(C.Structure):              # 104 bytes
+    _fields_ = [("layer_list", C.POINTER(LAYER)), ("layer_num", C.c_int),
+                ("bbox_list", C.POINTER(BBOX)), ("bbox_num", C.c_int), ("bbox_max", C.c_int),
+                ("s1", C.c_int), ("s2", C.c_int), ("weight_size", C.c_int),
+                ("weight_buf", f32p), ("cnntempbuf", f32p), ("cnnbufsize", C.c_int),
+                ("timeused", C.c_int * 8)]
+
+
+class FrameDets(C.Structure):        # ffgpu_frame_dets
+    _fields_ = [("count", C.c_int), ("ncand", C.c_int), ("overflow", C.c_int), ("reserved", C.c_int),
+                ("box", BBOX * FFGPU.MAX_DET)]
+
+
+assert C.sizeof(LAYER) == 120 and C.sizeof(NET) == 104 and C.sizeof(BBOX) == 24
+assert C.sizeof(FrameDets) == 16 + 24 * FFGPU.MAX_DET
+
+BOX_DTYPE = np.dtype([("type", "<i4"), ("score", "<f4"), ("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4")])
+DETS_DTYPE = np.dtype([("count", "<i4"), ("ncand", "<i4"), ("overflow", "<i4"), ("reserved", "<i4"),
+                       ("box", BOX_DTYPE, (FFGPU.MAX_DET,))])
+
+# every symbol include/*.h declares; tests check the built library exports all of them
+EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_profile", "groupconv",
+           "ffgpu_device_count", "ffgpu_set_device", "ffgpu_last_error", "ffgpu_build_info",
+           "ffgpu_net_weights_dev", "ffgpu_net_weights_commit",
+           "ffgpu_exec_create", "ffgpu_exec_destroy", "ffgpu_exec_batch", "ffgpu_exec_arena_bytes",
+           "ffgpu_exec_kernel_count", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
+           "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
+           "ffgpu_exec_profile", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev"]
+
+
+def library_path():
+    return os.path.join(HERE, "lib", "libffcnn_hip.so")
+
+
+def build_library(force=False):
+    """Compile libffcnn_hip.so in-tree (gcc + hipcc --offload-arch=gfx950)."""
+    cmd = ["make", "-C", os.path.join(HERE, "csrc")]
+    if force:
+        subprocess.check_call(cmd + ["clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return library_path()
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it was not built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP extension is the only compute path)" % path)
+    L = C.CDLL(path)
+    vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+    L.net_load.restype = C.POINTER(NET)
+    L.net_load.argtypes = [C.c_char_p, C.c_char_p, i, i]
+    L.net_free.argtypes = [C.POINTER(NET)]
+    L.net_input.argtypes = [C.POINTER(NET), vp, i, i, f32p, f32p]
+    L.net_forward.argtypes = [C.POINTER(NET)]
+    L.net_dump.argtypes = [C.POINTER(NET)]
+    L.net_profile.argtypes = [C.POINTER(NET)]
+    L.groupconv.argtypes = [f32p, f32p, f32p] + [i] * 12 + [C.POINTER(f32p), C.POINTER(i)]
+    L.ffgpu_last_error.restype = C.c_char_p
+    L.ffgpu_build_info.restype = C.c_char_p
+    L.ffgpu_set_device.argtypes = [i]
+    L.ffgpu_net_weights_dev.argtypes = [C.POINTER(NET), C.POINTER(vp), C.POINTER(sz)]
+    L.ffgpu_net_weights_commit.argtypes = [C.POINTER(NET), vp]
+    L.ffgpu_exec_create.restype = vp
+    L.ffgpu_exec_create.argtypes = [C.POINTER(NET), i, i]
+    L.ffgpu_exec_destroy.argtypes = [vp]
+    L.ffgpu_exec_batch.argtypes = [vp]
+    L.ffgpu_exec_arena_bytes.restype = sz
+    L.ffgpu_exec_arena_bytes.argtypes = [vp]
+    L.ffgpu_exec_kernel_count.argtypes = [vp]
+    L.ffgpu_exec_set_scale.argtypes = [vp, i, i]
+    L.ffgpu_exec_forward_dev.argtypes = [vp, vp, vp]
+    L.ffgpu_exec_forward_host.argtypes = [vp, f32p]
+    L.ffgpu_exec_forward_bgr_dev.argtypes = [vp, vp, i, i, f32p, f32p, vp]
+    L.ffgpu_exec_dets_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.ffgpu_exec_read_dets.argtypes = [vp, vp, i]
+    L.ffgpu_exec_read_layer.argtypes = [vp, i, i, f32p, sz]
+    L.ffgpu_exec_profile.argtypes = [vp, vp, f32p]
+    L.ffgpu_groupconv_dev.argtypes = [vp, vp, vp] + [i] * 15 + [vp]
+    L.ffgpu_groupconv_kernel_name.restype = C.c_char_p
+    L.ffgpu_groupconv_kernel_name.argtypes = [i] * 10
+    L.ffgpu_groupconv_time_dev.restype = C.c_float
+    L.ffgpu_groupconv_time_dev.argtypes = [vp, vp, vp] + [i] * 17 + [vp]
+    _lib = L
+    return L
+
+
+def load_bmp(path):
+    """24-bit BMP -> (bgr rows top-down with stride ALIGN(3w,4), w, h); what the demo feeds net_input."""
+    raw = open(path, "rb").read()
+    w, h = int.from_bytes(raw[18:22], "little"), int.from_bytes(raw[22:26], "little")
+    pitch = (w * 3 + 3) & ~3
+    rows = np.frombuffer(raw, np.uint8, pitch * h, 54).reshape(h, pitch)[::-1]
+    return np.ascontiguousarray(rows), w, h
+
+
+def last_error():
+    return lib().ffgpu_last_error().decode(errors="replace")
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise RuntimeError("%s failed: %s" % (what, last_error()))
+    return rc
+
+
+# ---- ffcnn.h mirror (same names / argument meaning as the reference) -------
+def net_load(cfg=CFG, weights=WEIGHTS, inputw=0, inputh=0):
+    """NET* or None (cfg unreadable, allocation failure, or no HIP device)."""
+    p = lib().net_load(cfg.encode() if cfg else None, weights.encode() if weights else None, inputw, inputh)
+    return p if p else None
+
+
+def net_free(net):
+    lib().net_free(net)
+
+
+def net_input(net, bgr, w, h, mean=(0.0, 0.0, 0.0), norm=(1 / 255.0, 1 / 255.0, 1 / 255.0)):
+    m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*norm)
+    lib().net_input(net, bgr.ctypes.data, w, h, m, s)
+
+
+def net_forward(net):
+    lib().net_forward(net)
+
+
+def net_dump(net):
+    lib().net_dump(net)
+
+
+def groupconv(x, filt, groups, pad, stride, fs, act):
+    """conv.h drop-in with host arrays: x (ic, ih, iw), filt (fn, K4+4) -> (fn, oh, ow)."""
+    ic, ih, iw = x.shape
+    fn = filt.shape[0]
+    oh, ow = (ih + 2 * pad - fs) // stride + 1, (iw + 2 * pad - fs) // stride + 1
+    x = np.ascontiguousarray(x, np.float32)
+    filt = np.ascontiguousarray(filt, np.float32)
+    out = np.full((fn, oh, ow), np.nan, np.float32)
+    buf, size = f32p(), C.c_int(0)
+    lib().groupconv(x.ctypes.data_as(f32p), filt.ctypes.data_as(f32p), out.ctypes.data_as(f32p),
+                    iw, ih, ic, groups, pad, stride, fs, fn, ow, oh, fn, act, C.byref(buf), C.byref(size))
+    return out
+
+
+def boxes_of(net):
+    n = net.contents
+    k = n.bbox_num
+    if k <= 0:
+        return np.zeros(0, BOX_DTYPE)
+    return np.frombuffer((BBOX * k).from_address(C.addressof(n.bbox_list.contents)), BOX_DTYPE, k).copy()
+
+
+# ---- convenience wrappers ---------------------------------------------------
+class Net:
+    """Owns a NET* (net_load/net_free) and exposes the layer table."""
+
+    def __init__(self, cfg=CFG, weights=WEIGHTS, w=0, h=0):
+        self.p = net_load(cfg, weights, w, h)
+        if self.p is None:
+            raise RuntimeError("net_load failed: %s" % last_error())
+        self.n = self.p.contents
+
+    def close(self):
+        if self.p is not None:
+            net_free(self.p)
+            self.p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def layer_num(self):
+        return self.n.layer_num
+
+    def layer(self, i):
+        return self.n.layer_list[i]
+
+    @property
+    def input_shape(self):
+        l0 = self.n.layer_list[0]
+        return (l0.c, l0.h, l0.w)
+
+    @property
+    def input(self):
+        return np.ctypeslib.as_array(self.n.layer_list[0].data, self.input_shape)
+
+    def set_input_image(self, bgr, w, h, mean=(0.0, 0.0, 0.0), norm=(1 / 255.0,) * 3):
+        self.input[...] = 0
+        net_input(self.p, bgr, w, h, mean, norm)
+
+    def forward(self):
+        net_forward(self.p)
+
+    @property
+    def boxes(self):
+        return boxes_of(self.p)
+
+    def out_shape(self, i):
+        o = self.n.layer_list[i + 1]
+        return (o.c, o.h, o.w)
+
+    def weights_host(self):
+        return np.ctypeslib.as_array(self.n.weight_buf, (self.n.weight_size,))
+
+    def weights_dev(self):
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        _check(lib().ffgpu_net_weights_dev(self.p, C.byref(ptr), C.byref(nbytes)), "ffgpu_net_weights_dev")
+        return ptr.value, nbytes.value
+
+    def weights_commit(self, stream=None):
+        _check(lib().ffgpu_net_weights_commit(self.p, stream), "ffgpu_net_weights_commit")
+
+    def executor(self, batch, flags=0):
+        return Executor(self, batch, flags)
+
+
+class Executor:
+    """A planned batched executor (ffgpu_exec_*)."""
+
+    def __init__(self, net, batch, flags=0):
+        self.net = net
+        self.h = lib().ffgpu_exec_create(net.p, batch, flags)
+        if not self.h:
+            raise RuntimeError("ffgpu_exec_create failed: %s" % last_error())
+        self.batch = batch
+        self.flags = flags
+
+    def close(self):
+        if self.h:
+            lib().ffgpu_exec_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def arena_bytes(self):
+        return lib().ffgpu_exec_arena_bytes(self.h)
+
+    @property
+    def kernel_count(self):
+        return lib().ffgpu_exec_kernel_count(self.h)
+
+    def set_scale(self, s1, s2):
+        _check(lib().ffgpu_exec_set_scale(self.h, s1, s2), "ffgpu_exec_set_scale")
+
+    def forward_dev(self, dev_ptr, stream=None):
+        _check(lib().ffgpu_exec_forward_dev(self.h, dev_ptr, stream), "ffgpu_exec_forward_dev")
+
+    def forward_host(self, frames):
+        frames = np.ascontiguousarray(frames, np.float32)
+        assert frames.shape == (self.batch,) + self.net.input_shape, frames.shape
+        _check(lib().ffgpu_exec_forward_host(self.h, frames.ctypes.data_as(f32p)), "ffgpu_exec_forward_host")
+
+    def forward_bgr_dev(self, dev_ptr, w, h, mean=(0.0, 0.0, 0.0), norm=(1 / 255.0,) * 3, stream=None):
+        m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*norm)
+        _check(lib().ffgpu_exec_forward_bgr_dev(self.h, dev_ptr, w, h, m, s, stream), "ffgpu_exec_forward_bgr_dev")
+
+    def dets_dev(self):
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        _check(lib().ffgpu_exec_dets_dev(self.h, C.byref(ptr), C.byref(nbytes)), "ffgpu_exec_dets_dev")
+        return ptr.value, nbytes.value
+
+    def read_dets(self):
+        out = np.zeros(self.batch, DETS_DTYPE)
+        _check(lib().ffgpu_exec_read_dets(self.h, out.ctypes.data, self.batch), "ffgpu_exec_read_dets")
+        return out
+
+    def boxes(self, frame=0, dets=None):
+        d = self.read_dets() if dets is None else dets
+        return d[frame]["box"][: d[frame]["count"]].copy()
+
+    def read_layer(self, layer, frame=0):
+        shape = self.net.out_shape(layer) if layer >= 0 else self.net.input_shape
+        out = np.empty(shape, np.float32)
+        _check(lib().ffgpu_exec_read_layer(self.h, layer, frame, out.ctypes.data_as(f32p), out.size), "ffgpu_exec_read_layer")
+        return out
+
+    def read_candidates(self, frame=0):
+        out = np.zeros(FFGPU.MAX_CAND, BOX_DTYPE)
+        n = _check(lib().ffgpu_exec_read_layer(self.h, -2, frame, out.ctypes.data_as(f32p), out.size * 6), "read candidates")
+        return out[:n].copy()
+
+    def profile(self, dev_ptr):
+        us = (C.c_float * 8)()
+        _check(lib().ffgpu_exec_profile(self.h, dev_ptr, us), "ffgpu_exec_profile")
+        return list(us)
+
+
+def groupconv_dev(d_in, d_filt, d_out, batch, iw, ih, ic, groups, pad, stride, fs, fn, act=0, flags=0, variant=0, stream=None):
+    ow, oh = (iw + 2 * pad - fs) // stride + 1, (ih + 2 * pad - fs) // stride + 1
+    _check(lib().ffgpu_groupconv_dev(d_in, d_filt, d_out, batch, iw, ih, ic, groups, pad, stride, fs, fn, ow, oh, fn,
+                                     act, flags, variant, stream), "ffgpu_groupconv_dev")
+
+
+def groupconv_time_dev(d_in, d_filt, d_out, batch, iw, ih, ic, groups, pad, stride, fs, fn, act=0, flags=0, variant=0,
+                       warmup=5, iters=20, stream=None):
+    ow, oh = (iw + 2 * pad - fs) // stride + 1, (ih + 2 * pad - fs) // stride + 1
+    us = lib().ffgpu_groupconv_time_dev(d_in, d_filt, d_out, batch, iw, ih, ic, groups, pad, stride, fs, fn, ow, oh, fn,
+                                        act, flags, variant, warmup, iters, stream)
+    if us < 0:
+        raise RuntimeError("ffgpu_groupconv_time_dev failed: %s" % last_error())
+    return us
+
+
+def kernel_name(batch, iw, ih, ic, groups, pad, stride, fs, fn, variant=0):
+    return lib().ffgpu_groupconv_kernel_name(batch, iw, ih, ic, groups, pad, stride, fs, fn, variant).decode()

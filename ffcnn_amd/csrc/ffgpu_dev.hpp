@@ -1,0 +1,57 @@
+// ffgpu_dev.hpp -- shared declarations of the HIP side of libffcnn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "ffgpu_internal.h"
+
+#define FFGPU_CHECK(expr)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            ffgpu_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -1;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+// One grouped convolution on device tensors.  Strides are in floats:
+// element (c, n, y, x) of the input lives at in + c*in_cs + n*in_ns + y*iw + x.
+// CNHW tensors have cs = N*h*w, ns = h*w; the frame-major batch input has
+// cs = h*w, ns = C*h*w.
+struct ConvDesc {
+    const float *in;
+    const float *filt;     // fn rows of K4+4 floats (conv.h layout)
+    float       *out;
+    const float *residual; // optional: out = act2(conv_act(...) + residual), same layout as out (fused shortcut)
+    int   N;
+    int   iw, ih, ic;
+    int   ow, oh, oc;
+    int   fs, stride, pad, groups;
+    int   act;            // activation of the conv itself
+    int   res_act;        // activation applied after adding the residual
+    int   flags;          // FFGPU_COMPAT_V6
+    long  in_cs, in_ns, out_cs, out_ns, res_cs, res_ns;
+};
+
+static inline int conv_k4(const ConvDesc &d) { return (d.fs * d.fs * (d.ic / d.groups) + 3) & ~3; }
+
+// kernels.hip
+int         ffgpu_launch_conv(const ConvDesc &d, int variant, hipStream_t s);
+const char *ffgpu_conv_kernel_name(const ConvDesc &d, int variant);
+int ffgpu_launch_pool(const float *in, float *out, int N, int c, int w, int h, int fs, int stride, int is_max, hipStream_t s);
+int ffgpu_launch_upsample(const float *in, float *out, long planes, int w, int h, int stride, hipStream_t s);
+int ffgpu_launch_add_act(const float *a, const float *b, float *out, long n, int act, hipStream_t s);
+int ffgpu_launch_copy(const float *src, float *dst, long n, hipStream_t s);
+int ffgpu_launch_input_bgr(const unsigned char *bgr, float *out, int N, int w, int h, int W, int H,
+                           int sw, int sh, int s1, int s2, const float mean[3], const float norm[3], hipStream_t s);
+
+struct YoloHead {
+    const float *in;       // CNHW, 3*(5+classes) channels
+    int   w, h, classes;
+    int   anchors[3][2];
+    float thresh, scale_xy;
+    int   key_base;        // emission-order key of this head's first candidate
+};
+int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, hipStream_t s);
+int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, const int *ncand, ffgpu_frame_dets *dets, int N,
+                     float thresh, int use_min, int s1, int s2, hipStream_t s);

@@ -1,0 +1,727 @@
+// ffgpu_exec.hip -- device executor of the ffcnn forward path + the C-ABI of ffcnn_hip.h.
+//
+// The reference walks its layer list once per frame, malloc()ing every output
+// tensor and free()ing inputs as a per-forward refcount drops to zero
+// (ffcnn.c:476-520).  Here the same liveness information is used ONCE, at plan
+// time: every tensor of a batch gets a fixed offset in a single HBM arena
+// (first-fit over lifetime intervals), the layer list becomes a static list of
+// kernel launches, and that list is captured into a HIP graph so a forward is a
+// single graph launch.  Plan-time rewrites (all disabled by FFGPU_NO_FUSE and
+// by FFGPU_KEEP_ALL):
+//   * dropout is a pointer alias (as in ffcnn.c:412-416),
+//   * a route with one source is an alias; a multi-source route becomes
+//     "concat in place": its sources are allocated inside the route's buffer
+//     (a CNHW channel concat is a concatenation of whole blocks),
+//   * conv -> [dropout] -> shortcut: the residual add moves into the conv epilogue.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ffgpu_dev.hpp"
+#include "conv.h"
+
+// --------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+extern "C" void ffgpu_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    if (getenv("FFGPU_VERBOSE")) fprintf(stderr, "ffgpu: %s\n", g_err);
+}
+
+extern "C" const char *ffgpu_last_error(void) { return g_err; }
+
+extern "C" const char *ffgpu_build_info(void)
+{
+    return "libffcnn_hip gfx950 (CDNA4) HIP " __DATE__ " " __TIME__;
+}
+
+extern "C" int ffgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+extern "C" int ffgpu_set_device(int ordinal)
+{
+    FFGPU_CHECK(hipSetDevice(ordinal));
+    return 0;
+}
+
+// --------------------------------------------------------------------------
+enum StepKind { S_CONV, S_POOL, S_UPSAMPLE, S_ADD, S_COPY, S_YOLO, S_NMS, S_CLEAR, S_TOCNHW };
+
+struct Step {
+    StepKind kind;
+    int      layer;          // reference layer index this step belongs to (-1: none)
+    int      ltype;          // LAYER_TYPE_* for profiling
+    ConvDesc conv;           // S_CONV (in == nullptr: patched to the batch input at launch)
+    bool     in_is_input;    // S_CONV / S_POOL / S_UPSAMPLE / S_TOCNHW read the batch input
+    const float *a, *b;      // generic sources
+    float   *out;
+    long     n;              // element count (ADD/COPY) or planes
+    int      w, h, c, fs, stride, flag;
+    YoloHead head;
+};
+
+struct Tensor {
+    long size = 0;           // floats
+    int  first = 1 << 30, last = -1;
+    long off = -1;           // arena offset (roots only)
+    int  parent = -1;        // concat-in-place parent tensor
+    long parent_off = 0;
+    bool used = false;
+};
+
+struct ffgpu_netdev {
+    NET   *net = nullptr;
+    float *d_weights = nullptr;
+    size_t weight_bytes = 0;
+    int    device = 0;
+    ffgpu_exec *exec1 = nullptr;
+};
+
+struct ffgpu_exec {
+    NET *net = nullptr;
+    ffgpu_netdev *dev = nullptr;
+    int  N = 1, flags = 0;
+    int  in_c = 0, in_h = 0, in_w = 0;
+    std::vector<Step>   steps;
+    std::vector<Tensor> tensors;       // index = layer id
+    std::vector<int>    canon;         // layer id -> tensor id holding its output (-1: the batch input, -2: none)
+    float *arena = nullptr;
+    size_t arena_floats = 0;
+    float *d_input = nullptr;          // own staging buffer for host / bgr entry points
+    BBOX  *d_cand = nullptr;
+    int   *d_cand_key = nullptr, *d_ncand = nullptr;
+    ffgpu_frame_dets *d_dets = nullptr;
+    int    s1 = 1, s2 = 1;
+    hipStream_t own_stream = nullptr, last_stream = nullptr;
+    // graph cache: one instantiated graph per (input pointer, s1, s2)
+    struct GraphKey { const float *in; int s1, s2; bool operator<(const GraphKey &o) const {
+        return in != o.in ? in < o.in : s1 != o.s1 ? s1 < o.s1 : s2 < o.s2; } };
+    std::map<GraphKey, hipGraphExec_t> graphs;
+    int kernel_count = 0;
+};
+
+static float *tensor_ptr(const ffgpu_exec *ex, int t)
+{
+    long off = 0;
+    while (ex->tensors[t].parent >= 0) { off += ex->tensors[t].parent_off; t = ex->tensors[t].parent; }
+    return ex->arena + ex->tensors[t].off + off;
+}
+
+static int root_of(const std::vector<Tensor> &ts, int t) { while (ts[t].parent >= 0) t = ts[t].parent; return t; }
+
+// -------------------------------------------------------------------------- planning
+static int plan(ffgpu_exec *ex)
+{
+    NET *net = ex->net;
+    const int L = net->layer_num, N = ex->N;
+    const bool keep_all = ex->flags & FFGPU_KEEP_ALL;
+    const bool fuse = !keep_all && !(ex->flags & FFGPU_NO_FUSE);
+    const LAYER *ll = net->layer_list;
+    std::vector<Tensor> &T = ex->tensors;
+    std::vector<int> &canon = ex->canon;
+    T.assign(L, Tensor());
+    canon.assign(L, -2);
+    auto out_floats = [&](int i) { return (long)ll[i + 1].w * ll[i + 1].h * ll[i + 1].c * N; };
+    auto src_tensor = [&](int i) { return i < 0 ? -1 : canon[i]; };          // tensor holding the output of layer i
+
+    // pass 1: aliases and shortcut fusion targets
+    std::vector<int> fused_into(L, -1);         // conv p -> shortcut s whose add it absorbs
+    std::vector<int> nuses(L, 0);               // consumers per LAYER output (before aliasing)
+    for (int i = 0; i < L; i++) {
+        if (i > 0 && ll[i].type != LAYER_TYPE_ROUTE) nuses[i - 1]++;
+        for (int k = 0; k < ll[i].depend_num; k++) {
+            const int d = ll[i].depend_list[k];
+            if (d < 0 || d >= i) { ffgpu_set_error("layer %d depends on layer %d (not earlier)", i, d); return -1; }
+            nuses[d]++;
+        }
+    }
+    for (int i = 0; i < L; i++) {
+        switch (ll[i].type) {
+        case LAYER_TYPE_DROPOUT: canon[i] = src_tensor(i - 1); break;
+        case LAYER_TYPE_YOLO: canon[i] = -2; break;
+        case LAYER_TYPE_ROUTE:
+            canon[i] = (ll[i].depend_num == 1 && src_tensor(ll[i].depend_list[0]) >= 0) ? src_tensor(ll[i].depend_list[0]) : i;
+            break;
+        default: canon[i] = i;
+        }
+        if (fuse && ll[i].type == LAYER_TYPE_SHORTCUT && i > 0) {
+            // walk back over dropouts to the producer of our input
+            int p = i - 1;
+            while (p > 0 && ll[p].type == LAYER_TYPE_DROPOUT && nuses[p] == 1) p--;
+            bool chain_private = ll[p].type == LAYER_TYPE_CONV && nuses[p] == 1 && src_tensor(ll[i].depend_list[0]) >= 0;
+            for (int q = p + 1; q < i && chain_private; q++) chain_private = ll[q].type == LAYER_TYPE_DROPOUT && nuses[q] == 1;
+            if (chain_private) { fused_into[p] = i; for (int q = p; q < i; q++) canon[q] = i; }
+        }
+    }
+    for (int i = 0; i < L; i++) if (canon[i] == i) { T[i].used = true; T[i].size = out_floats(i); }
+
+    // pass 2: concat-in-place for multi-source routes
+    std::vector<char> route_inplace(L, 0);
+    if (fuse) {
+        for (int i = 0; i < L; i++) {
+            if (ll[i].type != LAYER_TYPE_ROUTE || canon[i] != i || ll[i].depend_num < 2) continue;
+            bool ok = true;
+            std::vector<int> kids;
+            for (int k = 0; k < ll[i].depend_num && ok; k++) {
+                const int t = src_tensor(ll[i].depend_list[k]);
+                ok = t >= 0 && T[t].parent < 0 && std::find(kids.begin(), kids.end(), t) == kids.end();
+                kids.push_back(t);
+            }
+            if (!ok) continue;
+            long off = 0;
+            for (int t : kids) { T[t].parent = i; T[t].parent_off = off; off += T[t].size; }
+            route_inplace[i] = 1;
+        }
+    }
+
+    // pass 3: lifetimes (in layer-index time), folded onto concat roots
+    auto touch = [&](int t, int when) { if (t >= 0) { T[t].first = std::min(T[t].first, when); T[t].last = std::max(T[t].last, when); } };
+    for (int i = 0; i < L; i++) {
+        if (ll[i].type == LAYER_TYPE_DROPOUT) continue;
+        if (canon[i] >= 0 && !(ll[i].type == LAYER_TYPE_ROUTE && canon[i] != i)) touch(canon[i], i);     // written at i
+        if (ll[i].type != LAYER_TYPE_ROUTE) touch(src_tensor(i - 1), i);                                  // chain input read at i
+        for (int k = 0; k < ll[i].depend_num; k++) touch(src_tensor(ll[i].depend_list[k]), i);
+    }
+    for (int t = 0; t < L; t++) {
+        if (!T[t].used || T[t].parent < 0) continue;
+        const int r = root_of(T, t);
+        T[r].first = std::min(T[r].first, T[t].first);
+        T[r].last = std::max(T[r].last, T[t].last);
+    }
+
+    // pass 4: first-fit arena allocation of the roots, 256-byte granules
+    struct Live { long off, size; int last; };
+    std::vector<Live> live;
+    long high = 0;
+    std::vector<int> order;
+    for (int t = 0; t < L; t++) if (T[t].used && T[t].parent < 0) order.push_back(t);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return T[a].first != T[b].first ? T[a].first < T[b].first : a < b; });
+    for (int t : order) {
+        const long need = (T[t].size + 63) & ~63L;
+        if (keep_all) { T[t].off = high; high += need; continue; }
+        live.erase(std::remove_if(live.begin(), live.end(), [&](const Live &l) { return l.last < T[t].first; }), live.end());
+        std::sort(live.begin(), live.end(), [](const Live &a, const Live &b) { return a.off < b.off; });
+        long at = 0;
+        for (const Live &l : live) { if (at + need <= l.off) break; at = std::max(at, l.off + l.size); }
+        T[t].off = at;
+        live.push_back({ at, need, T[t].last });
+        high = std::max(high, at + need);
+    }
+    ex->arena_floats = (size_t)std::max(high, 64L);
+    if (hipMalloc(&ex->arena, ex->arena_floats * sizeof(float)) != hipSuccess) {
+        ffgpu_set_error("arena hipMalloc(%zu bytes) failed", ex->arena_floats * sizeof(float));
+        return -1;
+    }
+
+    // pass 5: steps
+    std::vector<Step> &S = ex->steps;
+    S.clear();
+    { Step c{}; c.kind = S_CLEAR; c.layer = -1; c.ltype = LAYER_TYPE_YOLO; S.push_back(c); }
+    int key_base = 0, nheads = 0;
+    float *cnhw_input = nullptr;     // set when the first layer cannot read the frame-major input directly
+    bool bad_chain = false;
+    auto in_ptr = [&](int i, bool *is_input) -> const float * {
+        const int t = src_tensor(i - 1);
+        *is_input = t == -1;
+        if (t < -1) bad_chain = true;            // e.g. a conv chained directly behind a yolo head
+        return t >= 0 ? tensor_ptr(ex, t) : nullptr;
+    };
+    for (int i = 0; i < L; i++) {
+        const LAYER &a = ll[i], &b = ll[i + 1];
+        Step st{};
+        st.layer = i; st.ltype = a.type;
+        bool from_input = false;
+        switch (a.type) {
+        case LAYER_TYPE_CONV: {
+            ConvDesc &d = st.conv;
+            st.kind = S_CONV;
+            d.in = in_ptr(i, &from_input);
+            st.in_is_input = from_input;
+            d.filt = ex->dev->d_weights + (a.filter - net->weight_buf);
+            d.out = tensor_ptr(ex, canon[i]);
+            d.N = N; d.iw = a.w; d.ih = a.h; d.ic = a.c; d.ow = b.w; d.oh = b.h; d.oc = b.c;
+            d.fs = a.fs; d.stride = a.stride; d.pad = a.pad; d.groups = a.groups; d.act = a.activation;
+            d.flags = ex->flags & FFGPU_COMPAT_V6;
+            if (from_input) { d.in_cs = (long)a.w * a.h; d.in_ns = (long)a.c * a.w * a.h; }     // frame-major batch input
+            else            { d.in_cs = (long)N * a.w * a.h; d.in_ns = (long)a.w * a.h; }
+            d.out_cs = (long)N * b.w * b.h; d.out_ns = (long)b.w * b.h;
+            if (fused_into[i] >= 0) {
+                const LAYER &sc = ll[fused_into[i]];
+                d.residual = tensor_ptr(ex, src_tensor(sc.depend_list[0]));
+                d.res_act = sc.activation; d.res_cs = d.out_cs; d.res_ns = d.out_ns;
+            }
+            S.push_back(st);
+            break; }
+        case LAYER_TYPE_AVGPOOL: case LAYER_TYPE_MAXPOOL: case LAYER_TYPE_UPSAMPLE: case LAYER_TYPE_SHORTCUT: {
+            const float *src = in_ptr(i, &from_input);
+            if (from_input && N > 1) {          // needs CNHW order: convert the input once
+                if (!cnhw_input) {
+                    if (hipMalloc(&cnhw_input, (size_t)a.w * a.h * a.c * N * sizeof(float)) != hipSuccess) { ffgpu_set_error("hipMalloc failed"); return -1; }
+                    Step cv{}; cv.kind = S_TOCNHW; cv.layer = -1; cv.ltype = a.type; cv.out = cnhw_input; cv.c = a.c; cv.w = a.w; cv.h = a.h; cv.in_is_input = true;
+                    S.push_back(cv);
+                }
+                src = cnhw_input; from_input = false;
+            }
+            st.in_is_input = from_input;
+            st.a = src;
+            if (a.type == LAYER_TYPE_SHORTCUT) {
+                if (canon[i - 1] == i) break;                       // absorbed by the producing conv
+                st.kind = S_ADD;
+                st.b = tensor_ptr(ex, src_tensor(a.depend_list[0]));
+                st.out = tensor_ptr(ex, canon[i]);
+                st.n = out_floats(i); st.flag = a.activation;
+            } else {
+                st.kind = a.type == LAYER_TYPE_UPSAMPLE ? S_UPSAMPLE : S_POOL;
+                st.out = tensor_ptr(ex, canon[i]);
+                st.c = a.c; st.w = a.w; st.h = a.h; st.fs = a.fs; st.stride = a.stride;
+                st.flag = a.type == LAYER_TYPE_MAXPOOL;
+            }
+            S.push_back(st);
+            break; }
+        case LAYER_TYPE_ROUTE: {
+            if (canon[i] != i || route_inplace[i]) break;           // alias / concat in place
+            long off = 0;
+            for (int k = 0; k < a.depend_num; k++) {
+                const int t = src_tensor(a.depend_list[k]);
+                if (t < 0) { ffgpu_set_error("route %d: unsupported source", i); return -1; }
+                const long cnt = (long)ll[a.depend_list[k] + 1].w * ll[a.depend_list[k] + 1].h * ll[a.depend_list[k] + 1].c * N;
+                Step cp{}; cp.kind = S_COPY; cp.layer = i; cp.ltype = a.type;
+                cp.a = tensor_ptr(ex, t); cp.out = tensor_ptr(ex, i) + off; cp.n = cnt;
+                S.push_back(cp);
+                off += cnt;
+            }
+            break; }
+        case LAYER_TYPE_YOLO: {
+            st.kind = S_YOLO;
+            YoloHead &hd = st.head;
+            hd.in = in_ptr(i, &from_input);
+            if (from_input) { ffgpu_set_error("yolo head directly on the input is not supported"); return -1; }
+            hd.w = a.w; hd.h = a.h; hd.classes = a.class_num;
+            memcpy(hd.anchors, a.anchor_list, sizeof hd.anchors);
+            hd.thresh = a.ignore_thres; hd.scale_xy = a.scale_x_y; hd.key_base = key_base;
+            key_base += a.w * a.h * 3;
+            nheads++;
+            S.push_back(st);
+            break; }
+        default: break;                                             // dropout
+        }
+    }
+    if (bad_chain) { ffgpu_set_error("a layer consumes the (non-existent) output of a yolo head"); return -1; }
+    { Step nm{}; nm.kind = S_NMS; nm.layer = -1; nm.ltype = LAYER_TYPE_YOLO; S.push_back(nm); }
+    ex->kernel_count = (int)S.size();
+    (void)nheads;
+    return 0;
+}
+
+// -------------------------------------------------------------------------- running
+static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hipStream_t s)
+{
+    switch (st.kind) {
+    case S_CLEAR:
+        FFGPU_CHECK(hipMemsetAsync(ex->d_ncand, 0, sizeof(int) * ex->N, s));
+        return 0;
+    case S_CONV: {
+        ConvDesc d = st.conv;
+        if (st.in_is_input) d.in = d_frames;
+        return ffgpu_launch_conv(d, FFGPU_K_AUTO, s); }
+    case S_POOL:
+        return ffgpu_launch_pool(st.in_is_input ? d_frames : st.a, st.out, ex->N, st.c, st.w, st.h, st.fs, st.stride, st.flag, s);
+    case S_UPSAMPLE:
+        return ffgpu_launch_upsample(st.in_is_input ? d_frames : st.a, st.out, (long)ex->N * st.c, st.w, st.h, st.stride, s);
+    case S_ADD:
+        return ffgpu_launch_add_act(st.in_is_input ? d_frames : st.a, st.b, st.out, st.n, st.flag, s);
+    case S_COPY:
+        return ffgpu_launch_copy(st.a, st.out, st.n, s);
+    case S_TOCNHW: {
+        // frame-major -> CNHW: a 1x1 "identity" regrouping expressed as strided plane copies
+        const long plane = (long)st.w * st.h;
+        for (int c = 0; c < st.c; c++)
+            FFGPU_CHECK(hipMemcpy2DAsync(st.out + (long)c * ex->N * plane, plane * sizeof(float),
+                                         d_frames + (long)c * plane, (size_t)st.c * plane * sizeof(float),
+                                         plane * sizeof(float), ex->N, hipMemcpyDeviceToDevice, s));
+        return 0; }
+    case S_YOLO:
+        return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand, s);
+    case S_NMS:
+        return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->d_dets, ex->N, 0.5f, 1, ex->s1, ex->s2, s);
+    }
+    return -1;
+}
+
+static int issue_all(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
+{
+    for (const Step &st : ex->steps)
+        if (issue_step(ex, st, d_frames, s) != 0) return -1;
+    return 0;
+}
+
+static int forward_on(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
+{
+    ex->last_stream = s;
+    if (ex->flags & FFGPU_NO_GRAPH) return issue_all(ex, d_frames, s);
+    ffgpu_exec::GraphKey key{ d_frames, ex->s1, ex->s2 };
+    auto it = ex->graphs.find(key);
+    if (it == ex->graphs.end()) {
+        if (ex->graphs.size() >= 8) {            // bound the cache: drop everything, rebuild on demand
+            for (auto &g : ex->graphs) (void)hipGraphExecDestroy(g.second);
+            ex->graphs.clear();
+        }
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t gexec = nullptr;
+        // capture on the executor's own stream (a user stream may be the legacy
+        // null stream, which cannot be captured); replay goes to `s`
+        hipStream_t cs = ex->own_stream;
+        FFGPU_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        const int rc = issue_all(ex, d_frames, cs);
+        hipError_t e = hipStreamEndCapture(cs, &graph);
+        if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return -1; }
+        if (e != hipSuccess) { ffgpu_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return -1; }
+        e = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { ffgpu_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return -1; }
+        it = ex->graphs.emplace(key, gexec).first;
+    }
+    FFGPU_CHECK(hipGraphLaunch(it->second, s));
+    return 0;
+}
+
+// -------------------------------------------------------------------------- C-ABI: executor
+static ffgpu_netdev *netdev_of(NET *net)
+{
+    if (!net) { ffgpu_set_error("NULL net"); return nullptr; }
+    ffcnn_ext *ext = ffcnn_ext_of(net);
+    if (!ext || !ext->dev) { ffgpu_set_error("net was not created by this library's net_load"); return nullptr; }
+    return (ffgpu_netdev *)ext->dev;
+}
+
+extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
+{
+    ffgpu_netdev *dev = netdev_of(net);
+    if (!dev) return nullptr;
+    if (batch < 1) { ffgpu_set_error("batch must be >= 1"); return nullptr; }
+    if (hipSetDevice(dev->device) != hipSuccess) { ffgpu_set_error("hipSetDevice failed"); return nullptr; }
+    const char *env = getenv("FFCNN_COMPAT_V6");
+    if (env && atoi(env)) flags |= FFGPU_COMPAT_V6;
+    env = getenv("FFGPU_NO_GRAPH");
+    if (env && atoi(env)) flags |= FFGPU_NO_GRAPH;
+    env = getenv("FFGPU_NO_FUSE");
+    if (env && atoi(env)) flags |= FFGPU_NO_FUSE;
+    ffgpu_exec *ex = new ffgpu_exec();
+    ex->net = net; ex->dev = dev; ex->N = batch; ex->flags = flags;
+    ex->in_c = net->layer_list[0].c; ex->in_h = net->layer_list[0].h; ex->in_w = net->layer_list[0].w;
+    bool ok = hipStreamCreateWithFlags(&ex->own_stream, hipStreamNonBlocking) == hipSuccess
+           && hipMalloc(&ex->d_cand, sizeof(BBOX) * FFGPU_MAX_CAND * (size_t)batch) == hipSuccess
+           && hipMalloc(&ex->d_cand_key, sizeof(int) * FFGPU_MAX_CAND * (size_t)batch) == hipSuccess
+           && hipMalloc(&ex->d_ncand, sizeof(int) * (size_t)batch) == hipSuccess
+           && hipMalloc(&ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess
+           && hipMemset(ex->d_dets, 0, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess;
+    if (!ok) { ffgpu_set_error("executor buffers: %s", hipGetErrorString(hipGetLastError())); ffgpu_exec_destroy(ex); return nullptr; }
+    if (plan(ex) != 0) { ffgpu_exec_destroy(ex); return nullptr; }
+    ex->last_stream = ex->own_stream;
+    return ex;
+}
+
+extern "C" void ffgpu_exec_destroy(ffgpu_exec *ex)
+{
+    if (!ex) return;
+    if (ex->last_stream) (void)hipStreamSynchronize(ex->last_stream);
+    for (auto &g : ex->graphs) (void)hipGraphExecDestroy(g.second);
+    for (const Step &st : ex->steps) if (st.kind == S_TOCNHW) (void)hipFree(st.out);
+    (void)hipFree(ex->arena); (void)hipFree(ex->d_input); (void)hipFree(ex->d_cand);
+    (void)hipFree(ex->d_cand_key); (void)hipFree(ex->d_ncand); (void)hipFree(ex->d_dets);
+    if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
+    delete ex;
+}
+
+extern "C" int ffgpu_exec_batch(const ffgpu_exec *ex) { return ex ? ex->N : 0; }
+extern "C" size_t ffgpu_exec_arena_bytes(const ffgpu_exec *ex) { return ex ? ex->arena_floats * sizeof(float) : 0; }
+extern "C" int ffgpu_exec_kernel_count(const ffgpu_exec *ex) { return ex ? ex->kernel_count : 0; }
+
+extern "C" int ffgpu_exec_set_scale(ffgpu_exec *ex, int s1, int s2)
+{
+    if (!ex || s2 == 0) { ffgpu_set_error("set_scale: bad arguments"); return -1; }
+    ex->s1 = s1; ex->s2 = s2;
+    return 0;
+}
+
+extern "C" int ffgpu_exec_forward_dev(ffgpu_exec *ex, const float *d_frames, void *stream)
+{
+    if (!ex || !d_frames) { ffgpu_set_error("forward_dev: NULL argument"); return -1; }
+    return forward_on(ex, d_frames, stream ? (hipStream_t)stream : ex->own_stream);
+}
+
+static int ensure_input(ffgpu_exec *ex)
+{
+    if (ex->d_input) return 0;
+    FFGPU_CHECK(hipMalloc(&ex->d_input, sizeof(float) * (size_t)ex->N * ex->in_c * ex->in_h * ex->in_w));
+    return 0;
+}
+
+extern "C" int ffgpu_exec_forward_host(ffgpu_exec *ex, const float *h_frames)
+{
+    if (!ex || !h_frames) { ffgpu_set_error("forward_host: NULL argument"); return -1; }
+    if (ensure_input(ex)) return -1;
+    const size_t bytes = sizeof(float) * (size_t)ex->N * ex->in_c * ex->in_h * ex->in_w;
+    FFGPU_CHECK(hipMemcpyAsync(ex->d_input, h_frames, bytes, hipMemcpyHostToDevice, ex->own_stream));
+    if (forward_on(ex, ex->d_input, ex->own_stream)) return -1;
+    FFGPU_CHECK(hipStreamSynchronize(ex->own_stream));
+    return 0;
+}
+
+extern "C" int ffgpu_exec_forward_bgr_dev(ffgpu_exec *ex, const unsigned char *d_bgr, int w, int h,
+                                          const float mean[3], const float norm[3], void *stream)
+{
+    if (!ex || !d_bgr || w <= 0 || h <= 0 || ex->in_c != 3) { ffgpu_set_error("forward_bgr_dev: bad arguments"); return -1; }
+    if (ensure_input(ex)) return -1;
+    hipStream_t s = stream ? (hipStream_t)stream : ex->own_stream;
+    const int W = ex->in_w, H = ex->in_h;
+    int sw, sh, s1, s2;                                          // ffcnn.c:267-273
+    if ((long)w * H > (long)h * W) { sw = W; sh = (int)((long)sw * h / w); s1 = w; s2 = sw; }
+    else                           { sh = H; sw = (int)((long)sh * w / h); s1 = h; s2 = sh; }
+    ex->s1 = s1; ex->s2 = s2;
+    if (ffgpu_launch_input_bgr(d_bgr, ex->d_input, ex->N, w, h, W, H, sw, sh, s1, s2, mean, norm, s)) return -1;
+    return forward_on(ex, ex->d_input, s);
+}
+
+extern "C" int ffgpu_exec_dets_dev(ffgpu_exec *ex, void **dev_ptr, size_t *bytes)
+{
+    if (!ex) { ffgpu_set_error("NULL executor"); return -1; }
+    if (dev_ptr) *dev_ptr = ex->d_dets;
+    if (bytes) *bytes = sizeof(ffgpu_frame_dets) * (size_t)ex->N;
+    return 0;
+}
+
+extern "C" int ffgpu_exec_read_dets(ffgpu_exec *ex, ffgpu_frame_dets *host_out, int max_frames)
+{
+    if (!ex || !host_out) { ffgpu_set_error("read_dets: NULL argument"); return -1; }
+    const int n = std::min(max_frames, ex->N);
+    FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
+    FFGPU_CHECK(hipMemcpy(host_out, ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)n, hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float *host_out, size_t cap_floats)
+{
+    if (!ex || !host_out || frame < 0 || frame >= ex->N) { ffgpu_set_error("read_layer: bad arguments"); return -1; }
+    FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
+    if (layer == -2) {                                            // candidates in reference emission order
+        int cnt = 0;
+        FFGPU_CHECK(hipMemcpy(&cnt, ex->d_ncand + frame, sizeof(int), hipMemcpyDeviceToHost));
+        cnt = std::min(cnt, FFGPU_MAX_CAND);
+        if ((size_t)cnt * 6 > cap_floats) { ffgpu_set_error("read_layer: buffer too small"); return -1; }
+        std::vector<BBOX> b(cnt);
+        std::vector<int> k(cnt), idx(cnt);
+        if (cnt) {
+            FFGPU_CHECK(hipMemcpy(b.data(), ex->d_cand + (size_t)frame * FFGPU_MAX_CAND, sizeof(BBOX) * cnt, hipMemcpyDeviceToHost));
+            FFGPU_CHECK(hipMemcpy(k.data(), ex->d_cand_key + (size_t)frame * FFGPU_MAX_CAND, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+        }
+        for (int i = 0; i < cnt; i++) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](int a, int c) { return k[a] < k[c]; });
+        for (int i = 0; i < cnt; i++) memcpy(host_out + 6 * i, &b[idx[i]], sizeof(BBOX));
+        return cnt;
+    }
+    if (!(ex->flags & FFGPU_KEEP_ALL)) { ffgpu_set_error("read_layer needs an FFGPU_KEEP_ALL executor"); return -1; }
+    if (layer < 0 || layer >= ex->net->layer_num || ex->canon[layer] < 0) { ffgpu_set_error("read_layer: layer %d has no tensor", layer); return -1; }
+    const LAYER &o = ex->net->layer_list[layer + 1];
+    const size_t plane = (size_t)o.w * o.h;
+    if (plane * o.c > cap_floats) { ffgpu_set_error("read_layer: buffer too small"); return -1; }
+    const float *src = tensor_ptr(ex, ex->canon[layer]) + (size_t)frame * plane;
+    FFGPU_CHECK(hipMemcpy2D(host_out, plane * sizeof(float), src, plane * ex->N * sizeof(float),
+                            plane * sizeof(float), o.c, hipMemcpyDeviceToHost));
+    return (int)(plane * o.c);
+}
+
+extern "C" int ffgpu_exec_profile(ffgpu_exec *ex, const float *d_frames, float us_by_kind[LAYER_TYPE_TOTOAL])
+{
+    if (!ex || !d_frames || !us_by_kind) { ffgpu_set_error("profile: NULL argument"); return -1; }
+    hipStream_t s = ex->own_stream;
+    std::vector<hipEvent_t> ev(ex->steps.size() + 1);
+    for (auto &e : ev) FFGPU_CHECK(hipEventCreate(&e));
+    if (issue_all(ex, d_frames, s)) return -1;                    // warm
+    FFGPU_CHECK(hipEventRecord(ev[0], s));
+    for (size_t i = 0; i < ex->steps.size(); i++) {
+        if (issue_step(ex, ex->steps[i], d_frames, s)) return -1;
+        FFGPU_CHECK(hipEventRecord(ev[i + 1], s));
+    }
+    FFGPU_CHECK(hipStreamSynchronize(s));
+    for (int k = 0; k < LAYER_TYPE_TOTOAL; k++) us_by_kind[k] = 0.f;
+    for (size_t i = 0; i < ex->steps.size(); i++) {
+        float ms = 0.f;
+        FFGPU_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        const int k = ex->steps[i].ltype;
+        if (k >= 0 && k < LAYER_TYPE_TOTOAL) us_by_kind[k] += ms * 1000.f;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    ex->last_stream = s;
+    return 0;
+}
+
+// -------------------------------------------------------------------------- C-ABI: net device state
+extern "C" void *ffgpu_netdev_create(NET *net)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        ffgpu_set_error("no HIP device visible: libffcnn_hip has no CPU fallback");
+        return nullptr;
+    }
+    ffgpu_netdev *dev = new ffgpu_netdev();
+    dev->net = net;
+    if (hipGetDevice(&dev->device) != hipSuccess) dev->device = 0;
+    dev->weight_bytes = sizeof(float) * (size_t)std::max(net->weight_size, 1);
+    if (hipMalloc(&dev->d_weights, dev->weight_bytes) != hipSuccess ||
+        hipMemcpy(dev->d_weights, net->weight_buf, sizeof(float) * (size_t)net->weight_size, hipMemcpyHostToDevice) != hipSuccess) {
+        ffgpu_set_error("weight upload failed: %s", hipGetErrorString(hipGetLastError()));
+        (void)hipFree(dev->d_weights);
+        delete dev;
+        return nullptr;
+    }
+    return dev;
+}
+
+extern "C" void ffgpu_netdev_destroy(void *p)
+{
+    ffgpu_netdev *dev = (ffgpu_netdev *)p;
+    if (!dev) return;
+    if (dev->exec1) ffgpu_exec_destroy(dev->exec1);
+    (void)hipFree(dev->d_weights);
+    delete dev;
+}
+
+extern "C" int ffgpu_netdev_forward1(NET *net, void *p)
+{
+    ffgpu_netdev *dev = (ffgpu_netdev *)p;
+    if (!dev->exec1) {
+        dev->exec1 = ffgpu_exec_create(net, 1, 0);
+        if (!dev->exec1) return -1;
+    }
+    ffgpu_exec *ex = dev->exec1;
+    ex->s1 = net->s1 ? net->s1 : 1;
+    ex->s2 = net->s2 ? net->s2 : 1;
+    if (ffgpu_exec_forward_host(ex, net->layer_list[0].data)) return -1;
+    static thread_local ffgpu_frame_dets rec;
+    if (ffgpu_exec_read_dets(ex, &rec, 1) != 1) return -1;
+    net->bbox_num = std::min(rec.count, net->bbox_max);
+    memcpy(net->bbox_list, rec.box, sizeof(BBOX) * FFGPU_MAX_DET);
+    if (rec.overflow) fprintf(stderr, "ffcnn: more than %d candidates or %d boxes in one frame; extras dropped\n", FFGPU_MAX_CAND, FFGPU_MAX_DET);
+    return 0;
+}
+
+extern "C" int ffgpu_net_weights_dev(NET *net, void **dev_ptr, size_t *bytes)
+{
+    ffgpu_netdev *dev = netdev_of(net);
+    if (!dev) return -1;
+    if (dev_ptr) *dev_ptr = dev->d_weights;
+    if (bytes) *bytes = sizeof(float) * (size_t)net->weight_size;
+    return 0;
+}
+
+extern "C" int ffgpu_net_weights_commit(NET *net, void *stream)
+{
+    ffgpu_netdev *dev = netdev_of(net);
+    if (!dev) return -1;
+    (void)stream;       // kernels read the filter rows in place: nothing derived to refresh yet
+    return 0;
+}
+
+// -------------------------------------------------------------------------- C-ABI: single conv on device tensors
+static void fill_desc(ConvDesc &d, const float *in, const float *filt, float *out, int batch,
+                      int iw, int ih, int ic, int groups, int pad, int stride, int fs, int ow, int oh, int oc, int act, int flags)
+{
+    memset(&d, 0, sizeof d);
+    d.in = in; d.filt = filt; d.out = out; d.N = batch;
+    d.iw = iw; d.ih = ih; d.ic = ic; d.ow = ow; d.oh = oh; d.oc = oc;
+    d.fs = fs; d.stride = stride; d.pad = pad; d.groups = groups; d.act = act; d.flags = flags & FFGPU_COMPAT_V6;
+    d.in_cs = (long)batch * iw * ih; d.in_ns = (long)iw * ih;
+    d.out_cs = (long)batch * ow * oh; d.out_ns = (long)ow * oh;
+}
+
+extern "C" int ffgpu_groupconv_dev(const float *d_in, const float *d_filt, float *d_out, int batch,
+                                   int iw, int ih, int ic, int groups, int pad, int stride,
+                                   int fs, int fn, int ow, int oh, int oc, int act,
+                                   int flags, int variant, void *stream)
+{
+    if (!d_in || !d_filt || !d_out || batch < 1 || fn != oc) { ffgpu_set_error("groupconv_dev: bad arguments"); return -1; }
+    ConvDesc d;
+    fill_desc(d, d_in, d_filt, d_out, batch, iw, ih, ic, groups, pad, stride, fs, ow, oh, oc, act, flags);
+    return ffgpu_launch_conv(d, variant, (hipStream_t)stream);
+}
+
+extern "C" const char *ffgpu_groupconv_kernel_name(int batch, int iw, int ih, int ic, int groups, int pad,
+                                                   int stride, int fs, int fn, int variant)
+{
+    ConvDesc d;
+    const int ow = (iw + 2 * pad - fs) / stride + 1, oh = (ih + 2 * pad - fs) / stride + 1;
+    fill_desc(d, nullptr, nullptr, nullptr, batch, iw, ih, ic, groups, pad, stride, fs, ow, oh, fn, 0, 0);
+    return ffgpu_conv_kernel_name(d, variant);
+}
+
+extern "C" float ffgpu_groupconv_time_dev(const float *d_in, const float *d_filt, float *d_out, int batch,
+                                          int iw, int ih, int ic, int groups, int pad, int stride,
+                                          int fs, int fn, int ow, int oh, int oc, int act,
+                                          int flags, int variant, int warmup, int iters, void *stream)
+{
+    if (iters < 1 || fn != oc) { ffgpu_set_error("groupconv_time_dev: bad arguments"); return -1.f; }
+    hipStream_t s = (hipStream_t)stream;
+    ConvDesc d;
+    fill_desc(d, d_in, d_filt, d_out, batch, iw, ih, ic, groups, pad, stride, fs, ow, oh, oc, act, flags);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { ffgpu_set_error("hipEventCreate failed"); return -1.f; }
+    for (int i = 0; i < warmup; i++) if (ffgpu_launch_conv(d, variant, s)) return -1.f;
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters; i++) if (ffgpu_launch_conv(d, variant, s)) return -1.f;
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) { ffgpu_set_error("hipEventSynchronize: %s", hipGetErrorString(hipGetLastError())); return -1.f; }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms * 1000.f / iters;
+}
+
+// -------------------------------------------------------------------------- conv.h drop-in (host pointers)
+// Literal replacement for a conv-vN.c object: stages through device scratch that
+// grows on demand and is kept for the life of the process (one per thread).
+struct HostConvScratch { float *in = nullptr, *filt = nullptr, *out = nullptr; size_t in_n = 0, filt_n = 0, out_n = 0; };
+
+static int grow(float **p, size_t *have, size_t need)
+{
+    if (*have >= need) return 0;
+    (void)hipFree(*p);
+    *p = nullptr; *have = 0;
+    FFGPU_CHECK(hipMalloc(p, need * sizeof(float)));
+    *have = need;
+    return 0;
+}
+
+extern "C" void groupconv(float *in, float *filt, float *out,
+                          int iw, int ih, int ic, int ig, int ipad, int istride,
+                          int fs, int fn, int ow, int oh, int oc, int act,
+                          float **scratch, int *scratch_floats)
+{
+    static thread_local HostConvScratch sc;
+    (void)scratch; (void)scratch_floats;          // the reference's callee-grown host scratch is not needed
+    if (!in || !filt || !out || ig < 1 || ic % ig) { fprintf(stderr, "ffcnn groupconv: bad arguments\n"); return; }
+    const size_t n_in = (size_t)iw * ih * ic, n_out = (size_t)ow * oh * oc;
+    const size_t n_f = (size_t)fn * ((((size_t)fs * fs * (ic / ig) + 3) & ~(size_t)3) + 4);
+    const char *env = getenv("FFCNN_COMPAT_V6");
+    const int flags = (env && atoi(env)) ? FFGPU_COMPAT_V6 : 0;
+    int rc = grow(&sc.in, &sc.in_n, n_in) || grow(&sc.filt, &sc.filt_n, n_f) || grow(&sc.out, &sc.out_n, n_out);
+    if (!rc) rc = hipMemcpy(sc.in, in, n_in * sizeof(float), hipMemcpyHostToDevice) != hipSuccess
+               || hipMemcpy(sc.filt, filt, n_f * sizeof(float), hipMemcpyHostToDevice) != hipSuccess;
+    if (!rc) rc = ffgpu_groupconv_dev(sc.in, sc.filt, sc.out, 1, iw, ih, ic, ig, ipad, istride, fs, fn, ow, oh, oc, act, flags, FFGPU_K_AUTO, nullptr);
+    if (!rc) rc = hipMemcpy(out, sc.out, n_out * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess;   // syncs the null stream
+    if (rc) fprintf(stderr, "ffcnn groupconv: device path failed: %s\n", g_err[0] ? g_err : hipGetErrorString(hipGetLastError()));
+}

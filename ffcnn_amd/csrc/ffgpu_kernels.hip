@@ -1,0 +1,353 @@
+// ffgpu_kernels.hip -- layer kernels of the ffcnn forward path for gfx950 (CDNA4).
+//
+// Every kernel works on CNHW device tensors (see ffcnn_hip.h) so that the batch
+// folds into the plane index: a depthwise plane, a pointwise pixel run and an
+// elementwise span are all contiguous regardless of the batch size.
+//
+// Reference arithmetic restated here (file:line into /root/reference):
+//   conv + folded BN + activation      conv-v0.c:7-31, utils.h:15-23
+//   max/avg pool                       ffcnn.c:337-394
+//   upsample / shortcut / route        ffcnn.c:396-434
+//   YOLO decode                        ffcnn.c:438-474
+//   NMS                                ffcnn.c:298-335
+//   net_input                          ffcnn.c:259-289
+#include "ffgpu_dev.hpp"
+
+#define WAVE 64
+
+__device__ __forceinline__ float act_apply(float x, int act)
+{
+    switch (act) {
+    case 1: return x > 0.f ? x : 0.f;
+    case 2: return x > 0.f ? x : 0.1f * x;
+    case 3: return 1.0f / (1.0f + (float)exp((double)-x));
+    default: return x;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Generic grouped convolution: one thread per output element, taps accumulated
+// in the reference's order (channel, tap row, tap column; conv-v0.c:14-24).
+// Covers every (fs, stride, pad, groups) the cfg grammar can express; the
+// specialised kernels below take over the shapes that matter for throughput.
+__global__ void k_conv_generic(ConvDesc d)
+{
+    const long total = (long)d.oc * d.N * d.oh * d.ow;
+    const int gic = d.ic / d.groups, goc = d.oc / d.groups;
+    const int k4 = (d.fs * d.fs * gic + 3) & ~3, rl = k4 + 4;
+    const bool v6dw5 = (d.flags & FFGPU_COMPAT_V6) && d.pad == 2 && d.fs == 5 && d.stride == 1 && gic == 1;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % d.ow);
+        long t = idx / d.ow;
+        const int y = (int)(t % d.oh); t /= d.oh;
+        const int n = (int)(t % d.N);
+        const int o = (int)(t / d.N);
+        const int g = o / goc;
+        const float *w = d.filt + (long)o * rl;
+        const float *src = d.in + (long)g * gic * d.in_cs + (long)n * d.in_ns;
+        float acc = 0.f;
+        for (int ci = 0; ci < gic; ci++) {
+            const float *pl = src + (long)ci * d.in_cs;
+            for (int ky = 0; ky < d.fs; ky++) {
+                if (v6dw5 && d.oh > 2 && y == d.oh - 2 && ky == 0) continue;   // conv-v6.c:422-441
+                const int sy = y * d.stride - d.pad + ky;
+                if ((unsigned)sy >= (unsigned)d.ih) continue;
+                for (int kx = 0; kx < d.fs; kx++) {
+                    const int sx = x * d.stride - d.pad + kx;
+                    if ((unsigned)sx >= (unsigned)d.iw) continue;
+                    acc = fmaf(pl[(long)sy * d.iw + sx], w[(ci * d.fs + ky) * d.fs + kx], acc);
+                }
+            }
+        }
+        float v = act_apply(fmaf(acc, w[k4], w[k4 + 1]), d.act);
+        const long ooff = (long)o * d.out_cs + (long)n * d.out_ns + (long)y * d.ow + x;
+        if (d.residual) v = act_apply(v + d.residual[(long)o * d.res_cs + (long)n * d.res_ns + (long)y * d.ow + x], d.res_act);
+        d.out[ooff] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pooling: window [x-(fs-1)/2, +fs) clipped to the plane (ffcnn.c:337-372)
+__global__ void k_pool(const float *in, float *out, long planes, int w, int h, int fs, int stride, int is_max)
+{
+    const int ow = w / stride, oh = h / stride;
+    const long total = planes * oh * ow;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % ow);
+        const long t = idx / ow;
+        const int oy = (int)(t % oh);
+        const float *p = in + (t / oh) * (long)w * h;
+        int x0 = ox * stride - (fs - 1) / 2, y0 = oy * stride - (fs - 1) / 2;
+        int x1 = min(x0 + fs, w), y1 = min(y0 + fs, h);
+        x0 = max(x0, 0); y0 = max(y0, 0);
+        float v = is_max ? p[y0 * w + x0] : 0.f;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const float q = p[y * w + x];
+                if (is_max) v = v < q ? q : v; else v += q;
+            }
+        out[idx] = is_max ? v : v / (float)(fs * fs);
+    }
+}
+
+__global__ void k_upsample(const float *in, float *out, long planes, int w, int h, int stride)
+{
+    const int ow = w * stride, oh = h * stride;
+    const long total = planes * oh * ow;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % ow);
+        const long t = idx / ow;
+        const int y = (int)(t % oh);
+        out[idx] = in[((t / oh) * h + y / stride) * w + x / stride];
+    }
+}
+
+// out = act(a + b), flat (ffcnn.c:418-423); 16-byte lanes with a scalar tail
+__global__ void k_add_act(const float *a, const float *b, float *out, long n, int act)
+{
+    const long n4 = n >> 2;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
+    for (long i = gid; i < n4; i += gsz) {
+        const float4 u = reinterpret_cast<const float4 *>(a)[i], v = reinterpret_cast<const float4 *>(b)[i];
+        float4 r;
+        r.x = act_apply(u.x + v.x, act); r.y = act_apply(u.y + v.y, act);
+        r.z = act_apply(u.z + v.z, act); r.w = act_apply(u.w + v.w, act);
+        reinterpret_cast<float4 *>(out)[i] = r;
+    }
+    for (long i = (n4 << 2) + gid; i < n; i += gsz) out[i] = act_apply(a[i] + b[i], act);
+}
+
+__global__ void k_copy(const float *src, float *dst, long n)
+{
+    const long n4 = n >> 2;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
+    for (long i = gid; i < n4; i += gsz) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(src)[i];
+    for (long i = (n4 << 2) + gid; i < n; i += gsz) dst[i] = src[i];
+}
+
+// batched net_input (ffcnn.c:259-289): u8 BGR -> planar RGB fp32, nearest
+// resize into the top-left sw x sh corner, zeros elsewhere.  Output is the
+// frame-major batch input (N x 3 x H x W).
+struct InputP { float mean[3], norm[3]; };
+__global__ void k_input_bgr(const unsigned char *bgr, float *out, int N, int w, int h, int W, int H,
+                            int sw, int sh, int s1, int s2, InputP p)
+{
+    const long total = (long)N * H * W;
+    const long pitch = (long)((w * 3 + 3) & ~3);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        const long t = idx / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        float r = 0.f, g = 0.f, b = 0.f;
+        if (x < sw && y < sh) {
+            const unsigned char *px = bgr + (long)n * pitch * h + (long)((long)y * s1 / s2) * pitch + (long)((long)x * s1 / s2) * 3;
+            r = ((float)px[2] - p.mean[0]) * p.norm[0];
+            g = ((float)px[1] - p.mean[1]) * p.norm[1];
+            b = ((float)px[0] - p.mean[2]) * p.norm[2];
+        }
+        float *o = out + (long)n * 3 * H * W + (long)y * W + x;
+        o[0] = r; o[(long)H * W] = g; o[2L * H * W] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// YOLO head decode (ffcnn.c:438-474).  One thread per (frame, cell, anchor);
+// lanes run along x so the 85 strided channel reads are coalesced.  exp() is
+// evaluated in double and narrowed exactly where the reference does, and FMA
+// contraction is off so the confidence/box arithmetic rounds like the C code.
+__global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand)
+{
+#pragma clang fp contract(off)
+    const int cells = hd.w * hd.h;
+    const long total = (long)N * 3 * cells;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int cell = (int)(gid % cells);
+    const int k = (int)((gid / cells) % 3);
+    const int n = (int)(gid / (3L * cells));
+    const int j = cell % hd.w, i = cell / hd.w;
+    const long cs = (long)N * cells;                                  // CNHW channel stride
+    const float *p = hd.in + (long)k * (5 + hd.classes) * cs + (long)n * cells + cell;
+    const float bs = p[4 * cs];
+    float cs_best = p[5 * cs];
+    int best = 0;
+    for (int l = 1; l < hd.classes; l++) {
+        const float v = p[(5 + l) * cs];
+        if (cs_best < v) { cs_best = v; best = l; }
+    }
+    const float conf = 1.0f / ((1.0f + (float)exp((double)-bs) * (1.0f + (float)exp((double)-cs_best))));
+    if (!(conf >= hd.thresh)) return;
+    const float tx = p[0], ty = p[cs], tw = p[2 * cs], th = p[3 * cs];
+    const float sx = 1.0f / (1.0f + (float)exp((double)-tx));
+    const float sy = 1.0f / (1.0f + (float)exp((double)-ty));
+    const float cx = (j + sx) * netw / hd.w;
+    const float cy = (i + sy) * neth / hd.h;
+    const float bw = (float)exp((double)tw) * hd.anchors[k][0] * hd.scale_xy;
+    const float bh = (float)exp((double)th) * hd.anchors[k][1] * hd.scale_xy;
+    const int slot = atomicAdd(&ncand[n], 1);
+    if (slot >= FFGPU_MAX_CAND) return;
+    BBOX b;
+    b.type = best; b.score = conf;
+    b.x1 = cx - bw * 0.5f; b.y1 = cy - bh * 0.5f;
+    b.x2 = cx + bw * 0.5f; b.y2 = cy + bh * 0.5f;
+    cand[(long)n * FFGPU_MAX_CAND + slot] = b;
+    cand_key[(long)n * FFGPU_MAX_CAND + slot] = hd.key_base + cell * 3 + k;   // reference emission order
+}
+
+// NMS (ffcnn.c:298-335): one workgroup per frame.  Candidates are ordered by
+// (score desc, emission key asc) with a bitonic sort in LDS -- the key makes the
+// order total where qsort's is unspecified -- then suppressed greedily per class
+// with inter/min(area) (or IoU) > thresh, compacted and rescaled by s1/s2.
+__global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_key, const int *ncand,
+                                             ffgpu_frame_dets *dets, float thresh, int use_min, int s1, int s2)
+{
+#pragma clang fp contract(off)
+    __shared__ float s_score[FFGPU_MAX_CAND];
+    __shared__ int   s_key[FFGPU_MAX_CAND];
+    __shared__ short s_idx[FFGPU_MAX_CAND];
+    __shared__ unsigned char s_alive[FFGPU_MAX_CAND];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int total = ncand[n];
+    const int m = min(total, FFGPU_MAX_CAND);
+    const BBOX *c = cand + (long)n * FFGPU_MAX_CAND;
+    ffgpu_frame_dets *out = dets + n;
+    int pow2 = 1;
+    while (pow2 < m) pow2 <<= 1;
+    for (int i = tid; i < pow2; i += blockDim.x) {
+        s_score[i] = i < m ? c[i].score : -1.f;
+        s_key[i] = i < m ? cand_key[(long)n * FFGPU_MAX_CAND + i] : 0x7fffffff;
+        s_idx[i] = (short)i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= pow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < pow2; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    // "a precedes b": higher score first, then lower key
+                    const bool a_first = s_score[i] > s_score[l] || (s_score[i] == s_score[l] && s_key[i] < s_key[l]);
+                    if (a_first != up) {
+                        const float ts = s_score[i]; s_score[i] = s_score[l]; s_score[l] = ts;
+                        const int tk = s_key[i]; s_key[i] = s_key[l]; s_key[l] = tk;
+                        const short ti = s_idx[i]; s_idx[i] = s_idx[l]; s_idx[l] = ti;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < m; i += blockDim.x) s_alive[i] = 1;
+    __syncthreads();
+    for (int a = 0; a < m; a++) {
+        if (!s_alive[a]) continue;                       // uniform: read after a barrier
+        const BBOX ba = c[s_idx[a]];
+        const float area_a = (ba.x2 - ba.x1) * (ba.y2 - ba.y1);
+        for (int j = a + 1 + tid; j < m; j += blockDim.x) {
+            if (!s_alive[j]) continue;
+            const BBOX bj = c[s_idx[j]];
+            if (bj.type != ba.type) continue;
+            const float xa = ba.x1 > bj.x1 ? ba.x1 : bj.x1, ya = ba.y1 > bj.y1 ? ba.y1 : bj.y1;
+            const float xb = ba.x2 < bj.x2 ? ba.x2 : bj.x2, yb = ba.y2 < bj.y2 ? ba.y2 : bj.y2;
+            const float inter = (xa < xb && ya < yb) ? (xb - xa) * (yb - ya) : 0.f;
+            const float area_j = (bj.x2 - bj.x1) * (bj.y2 - bj.y1);
+            const float uni = area_a + area_j - inter;
+            const float metric = use_min ? inter / (area_a < area_j ? area_a : area_j) : inter / uni;
+            if (metric > thresh) s_alive[j] = 0;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int keep = 0, clipped = 0;
+        for (int i = 0; i < m; i++) {
+            if (!s_alive[i]) continue;
+            if (keep == FFGPU_MAX_DET) { clipped = 1; break; }
+            const BBOX b = c[s_idx[i]];
+            BBOX r;
+            r.type = b.type; r.score = b.score;
+            r.x1 = b.x1 * s1 / s2; r.y1 = b.y1 * s1 / s2;
+            r.x2 = b.x2 * s1 / s2; r.y2 = b.y2 * s1 / s2;
+            out->box[keep++] = r;
+        }
+        out->count = keep;
+        out->ncand = total;
+        out->overflow = (total > FFGPU_MAX_CAND) | clipped;
+        out->reserved = 0;
+        const BBOX z = { 0, 0.f, 0.f, 0.f, 0.f, 0.f };
+        for (int i = keep; i < FFGPU_MAX_DET; i++) out->box[i] = z;     // reference zeroes the tail (ffcnn.c:333)
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+static inline int grid_for(long total, int block, int cap = 256 * 16)
+{
+    long g = (total + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+#define LAUNCH_OK(what)                                                                      \
+    do {                                                                                     \
+        hipError_t e_ = hipGetLastError();                                                   \
+        if (e_ != hipSuccess) { ffgpu_set_error("%s launch failed: %s", what, hipGetErrorString(e_)); return -1; } \
+    } while (0)
+
+#include "ffgpu_conv_kernels.inc"
+
+int ffgpu_launch_pool(const float *in, float *out, int N, int c, int w, int h, int fs, int stride, int is_max, hipStream_t s)
+{
+    if (stride < 1 || fs < 1) { ffgpu_set_error("pool: bad size/stride"); return -1; }
+    const long planes = (long)N * c, total = planes * (h / stride) * (w / stride);
+    hipLaunchKernelGGL(k_pool, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, planes, w, h, fs, stride, is_max);
+    LAUNCH_OK("pool");
+    return 0;
+}
+
+int ffgpu_launch_upsample(const float *in, float *out, long planes, int w, int h, int stride, hipStream_t s)
+{
+    const long total = planes * h * stride * w * stride;
+    hipLaunchKernelGGL(k_upsample, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, planes, w, h, stride);
+    LAUNCH_OK("upsample");
+    return 0;
+}
+
+int ffgpu_launch_add_act(const float *a, const float *b, float *out, long n, int act, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_add_act, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, s, a, b, out, n, act);
+    LAUNCH_OK("add_act");
+    return 0;
+}
+
+int ffgpu_launch_copy(const float *src, float *dst, long n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_copy, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, s, src, dst, n);
+    LAUNCH_OK("copy");
+    return 0;
+}
+
+int ffgpu_launch_input_bgr(const unsigned char *bgr, float *out, int N, int w, int h, int W, int H,
+                           int sw, int sh, int s1, int s2, const float mean[3], const float norm[3], hipStream_t s)
+{
+    InputP p;
+    for (int i = 0; i < 3; i++) { p.mean[i] = mean[i]; p.norm[i] = norm[i]; }
+    hipLaunchKernelGGL(k_input_bgr, dim3(grid_for((long)N * H * W, 256)), dim3(256), 0, s, bgr, out, N, w, h, W, H, sw, sh, s1, s2, p);
+    LAUNCH_OK("input_bgr");
+    return 0;
+}
+
+int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, hipStream_t s)
+{
+    const long total = (long)N * 3 * hd.w * hd.h;
+    hipLaunchKernelGGL(k_yolo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hd, N, netw, neth, cand, cand_key, ncand);
+    LAUNCH_OK("yolo");
+    return 0;
+}
+
+int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, const int *ncand, ffgpu_frame_dets *dets, int N,
+                     float thresh, int use_min, int s1, int s2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_nms, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, dets, thresh, use_min, s1, s2);
+    LAUNCH_OK("nms");
+    return 0;
+}

@@ -1,0 +1,143 @@
+/*
+ * ffcnn_hip.h -- additive, device-resident / batched C-ABI of libffcnn_hip.so.
+ *
+ * ffcnn.h and conv.h keep the reference's host-pointer interfaces (one frame,
+ * H2D + D2H around every call).  Nothing in the reference has a batch
+ * dimension or a device boundary, so the entry points below
+ * are new names; each one states which reference code path it is the batched
+ * counterpart of.  Plain C types only: pointers, sizes, ints.
+ *
+ * Device tensor layout ("CNHW"): a tensor of C channels for a batch of N frames
+ * is C*N contiguous planes of H*W fp32, plane (c, n) at ((c*N + n)*H*W).  For
+ * N == 1 this is exactly the reference's planar CHW tensor (ffcnn.c:436).  The
+ * batch INPUT is the exception: frames are handed over frame-major, N x C x H x W
+ * (each frame is one reference input tensor), and the first layer reads that.
+ *
+ * Error convention: functions returning int give 0 on success, negative on
+ * failure; ffgpu_last_error() describes the last failure on the calling thread.
+ * There is no CPU fallback anywhere: without a HIP device every call fails.
+ */
+#ifndef FFCNN_AMD_FFCNN_HIP_H
+#define FFCNN_AMD_FFCNN_HIP_H
+
+#include <stddef.h>
+#include "ffcnn.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFGPU_MAX_DET   128   /* final boxes kept per frame (reference: bbox_max, ffcnn.c:243) */
+#define FFGPU_MAX_CAND  1024  /* pre-NMS candidates kept per frame                            */
+
+/* Per-frame detection record as it lies in device (and gathered host) memory.
+ * This is the unit the multi-GPU gather moves: fixed size, 16 + 128*24 bytes. */
+typedef struct {
+    int  count;               /* boxes valid in box[] (post-NMS, source-image coords)  */
+    int  ncand;               /* candidates that passed ignore_thresh before NMS       */
+    int  overflow;            /* nonzero if ncand > FFGPU_MAX_CAND or count clipped    */
+    int  reserved;
+    BBOX box[FFGPU_MAX_DET];
+} ffgpu_frame_dets;
+
+typedef struct ffgpu_exec ffgpu_exec;     /* a planned executor: one NET x one batch size */
+
+/* executor flags */
+#define FFGPU_KEEP_ALL   1    /* one buffer per layer (no arena reuse): per-layer read-back  */
+#define FFGPU_COMPAT_V6  2    /* reproduce conv-v6.c:422-441 (5x5 depthwise row oh-2 defect) */
+#define FFGPU_NO_GRAPH   4    /* launch kernels eagerly instead of replaying a HIP graph     */
+#define FFGPU_NO_FUSE    8    /* one kernel per reference layer (no cross-layer fusion)      */
+
+/* ---- process / device --------------------------------------------------- */
+int         ffgpu_device_count(void);
+int         ffgpu_set_device(int ordinal);            /* hipSetDevice for this thread        */
+const char *ffgpu_last_error(void);
+const char *ffgpu_build_info(void);                   /* "gfx950 ... <git describe/date>"    */
+
+/* ---- weights (counterpart of ffcnn.c:211-239's weight_buf, in HBM) ------ */
+/* Device address and byte size of the folded filter rows (same layout as
+ * NET.weight_buf).  This is the buffer a multi-GPU job broadcasts (RCCL). */
+int ffgpu_net_weights_dev(NET *net, void **dev_ptr, size_t *bytes);
+/* Call after writing the device weights from outside (e.g. after a broadcast):
+ * refreshes derived device-side packings.  Runs on `stream` (hipStream_t or NULL). */
+int ffgpu_net_weights_commit(NET *net, void *stream);
+
+/* ---- batched forward (counterpart of net_forward, ffcnn.c:476-520) ------ */
+ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags);
+void        ffgpu_exec_destroy(ffgpu_exec *ex);
+int         ffgpu_exec_batch(const ffgpu_exec *ex);
+size_t      ffgpu_exec_arena_bytes(const ffgpu_exec *ex);
+int         ffgpu_exec_kernel_count(const ffgpu_exec *ex);   /* launches per forward */
+
+/* Box rescale ratio for every frame of the batch (what net_input derives per
+ * image, ffcnn.c:267-273).  Default s1 = s2 = 1 (boxes in network pixels). */
+int ffgpu_exec_set_scale(ffgpu_exec *ex, int s1, int s2);
+
+/* d_frames: device pointer, batch x C x H x W fp32 (frame-major).  Enqueues the
+ * whole net + YOLO decode + NMS on `stream` (hipStream_t; NULL = the executor's
+ * own stream) and returns without synchronising. */
+int ffgpu_exec_forward_dev(ffgpu_exec *ex, const float *d_frames, void *stream);
+
+/* Same, from host memory (H2D copy included), then waits for completion. */
+int ffgpu_exec_forward_host(ffgpu_exec *ex, const float *h_frames);
+
+/* u8 BGR frames on the device (batch x h x ALIGN(3w,4) bytes, all the same size)
+ * -> letterboxed fp32 input + forward: the batched net_input (ffcnn.c:259-289)
+ * fused in front of the net.  Sets the scale from (w,h) like net_input does. */
+int ffgpu_exec_forward_bgr_dev(ffgpu_exec *ex, const unsigned char *d_bgr, int w, int h,
+                               const float mean[3], const float norm[3], void *stream);
+
+/* Device address of the batch's ffgpu_frame_dets[batch] (valid after the
+ * forward enqueued on the same stream completes). */
+int ffgpu_exec_dets_dev(ffgpu_exec *ex, void **dev_ptr, size_t *bytes);
+/* Synchronise the executor's last stream and copy the records to the host. */
+int ffgpu_exec_read_dets(ffgpu_exec *ex, ffgpu_frame_dets *host_out, int max_frames);
+
+/* FFGPU_KEEP_ALL executors only: copy layer `layer`'s OUTPUT for frame `frame`
+ * into host_out (oc*oh*ow floats, reference CHW order).  layer == -1 gives the
+ * network input as the first layer saw it.  Pre-NMS candidates: layer == -2
+ * writes up to FFGPU_MAX_CAND BBOX (in network pixels, reference emission
+ * order) and returns their count. */
+int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float *host_out, size_t cap_floats);
+
+/* Mean device time per layer KIND over the last profiled forward, in micro-
+ * seconds, indexed by LAYER_TYPE_* (counterpart of ENABLE_NET_PROFILE,
+ * ffcnn.c:33,494-510).  Runs one eager forward with hipEvents around each step. */
+int ffgpu_exec_profile(ffgpu_exec *ex, const float *d_frames, float us_by_kind[LAYER_TYPE_TOTOAL]);
+
+/* ---- single operators on device tensors (CNHW, any batch) --------------- */
+/* Counterpart of groupconv (conv.h:4-7) without the host round trip.  d_in is
+ * ic*batch planes of ih*iw, d_out oc*batch planes of oh*ow; d_filt as conv.h.
+ * variant: 0 = auto (what the executor would pick), otherwise a specific kernel
+ * id (FFGPU_K_*) for testing/benchmarking; unsupported combinations fail. */
+int ffgpu_groupconv_dev(const float *d_in, const float *d_filt, float *d_out, int batch,
+                        int iw, int ih, int ic, int groups, int pad, int stride,
+                        int fs, int fn, int ow, int oh, int oc, int act,
+                        int flags, int variant, void *stream);
+
+enum {
+    FFGPU_K_AUTO = 0,
+    FFGPU_K_GENERIC = 1,      /* any fs/stride/pad/groups: one thread per output          */
+    FFGPU_K_DW_STREAM = 2,    /* depthwise 3x3 s1: register sliding window, 16 B loads    */
+    FFGPU_K_DW_LDS = 3,       /* depthwise 3x3/5x5, s1/s2: whole planes staged in LDS     */
+    FFGPU_K_PW_MFMA = 4,      /* 1x1: fp32 MFMA 16x16x4, streaming (bandwidth-bound)      */
+    FFGPU_K_PW_GEMM = 5,      /* 1x1: LDS-tiled fp32 MFMA 32x32x2 GEMM (compute-bound)    */
+    FFGPU_K_PW_VALU = 6       /* 1x1: plain VALU FMA (baseline / tiny channel counts)     */
+};
+
+/* name of the kernel `variant` resolves to for this shape (for logs/benches) */
+const char *ffgpu_groupconv_kernel_name(int batch, int iw, int ih, int ic, int groups, int pad,
+                                        int stride, int fs, int fn, int variant);
+
+/* Times `iters` launches of one conv on `stream` with hipEvents recorded on that
+ * stream (after `warmup` untimed launches); returns mean microseconds per launch
+ * or a negative value on error. */
+float ffgpu_groupconv_time_dev(const float *d_in, const float *d_filt, float *d_out, int batch,
+                               int iw, int ih, int ic, int groups, int pad, int stride,
+                               int fs, int fn, int ow, int oh, int oc, int act,
+                               int flags, int variant, int warmup, int iters, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFCNN_AMD_FFCNN_HIP_H */

@@ -1,0 +1,55 @@
+"""CPU-side checks of the C-ABI boundary: the library builds, loads, exports every
+symbol include/*.h declares, and refuses to run without a GPU (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from ffcnn_amd import capi as m
+    m.build_library()
+    return m
+
+
+def test_headers_and_exports_agree(capi):
+    L = capi.lib()
+    declared = set()
+    for h in ("ffcnn.h", "conv.h", "ffcnn_hip.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        declared |= set(re.findall(r"\b((?:net|ffgpu)_[a-z0-9_]+|groupconv)\s*\(", txt))
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+
+
+def test_struct_abi(capi):
+    import ctypes as C
+    assert (C.sizeof(capi.LAYER), C.sizeof(capi.BBOX), C.sizeof(capi.NET)) == (120, 24, 104)
+    assert capi.LAYER.data.offset == 8 and capi.LAYER.filter.offset == 16 and capi.LAYER.w.offset == 24
+    assert capi.LAYER.depend_list.offset == 64 and capi.LAYER.class_num.offset == 84 and capi.LAYER.scale_x_y.offset == 116
+    assert capi.NET.bbox_list.offset == 16 and capi.NET.weight_buf.offset == 48 and capi.NET.timeused.offset == 68
+
+
+def test_no_cpu_fallback(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert capi.lib().ffgpu_device_count() == 0
+    assert capi.net_load() is None
+    assert "no HIP device" in capi.last_error()
+    assert capi.net_load("/nonexistent.cfg", None) is None
+    assert "cannot read cfg" in capi.last_error()
+
+
+def test_product_does_not_touch_oracle():
+    """The product package and its C sources never reference oracle/ (parity would be void)."""
+    for base, _, files in os.walk(os.path.join(ROOT, "ffcnn_amd")):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hpp", ".hip", ".inc", "Makefile")):
+                txt = open(os.path.join(base, f), errors="replace").read()
+                assert "oracle" not in txt.lower() or f == "__init__.py" and False, os.path.join(base, f)

@@ -1,0 +1,220 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle and the
+reference's golden vectors.  Tolerance for fp32 activations:
+|d| <= 1e-3 + 1e-3*|ref|; boxes within 0.05 px, scores within 1e-4, same class/count."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+
+pytestmark = pytest.mark.gpu
+
+ATOL, RTOL = 1e-3, 1e-3
+
+
+def close(a, ref, what=""):
+    err = np.abs(a - ref) - (ATOL + RTOL * np.abs(ref))
+    assert err.max() <= 0, "%s: max excess %.3g (max |d| %.3g)" % (what, err.max(), np.abs(a - ref).max())
+
+
+def boxes_match(got, want, what=""):
+    assert len(got) == len(want), "%s: %d vs %d boxes" % (what, len(got), len(want))
+    for g, w in zip(got, want):
+        assert int(g["type"]) == int(w["type"]), what
+        assert abs(float(g["score"]) - float(w["score"])) <= 1e-4, what
+        for k in ("x1", "y1", "x2", "y2"):
+            assert abs(float(g[k]) - float(w[k])) <= 0.05, what
+
+
+@pytest.fixture(scope="module")
+def F():
+    import ffcnn_amd
+    from ffcnn_amd import capi
+    capi.lib()
+    return capi
+
+
+@pytest.fixture(scope="module")
+def net(F):
+    n = F.Net()
+    yield n
+    n.close()
+
+
+@pytest.fixture(scope="module")
+def frames(orc, test_image):
+    """frame 0: letterboxed test.bmp (as net_input makes it); 1..3: seeded noise / edge content."""
+    bgr, w, h = test_image
+    o = orc.Oracle()
+    o.set_input_image(bgr, w, h)
+    rng = np.random.default_rng(1236)
+    fr = np.zeros((4, 3, 320, 320), np.float32)
+    fr[0] = o.input
+    fr[1] = rng.uniform(0, 1, (3, 320, 320))
+    fr[2] = np.roll(o.input, 37, axis=2)           # shifted image: different detections
+    fr[3] = 0.0                                     # all-zero frame
+    o.close()
+    return fr
+
+
+@pytest.fixture(scope="module")
+def oracle_runs(orc, frames):
+    """oracle activations, candidates and boxes per frame (s1 = s2 = 1 -> network pixels)."""
+    res = []
+    o = orc.Oracle()
+    for f in frames:
+        o.input[...] = f
+        o.n.s1, o.n.s2 = 1, 1
+        o.forward(0)
+        acts = {i: o.layer_out(i).copy() for i in range(o.nlayers) if o.layer_out(i) is not None}
+        res.append(dict(acts=acts, cand=o.candidates, boxes=o.boxes))
+    o.close()
+    return res
+
+
+def test_groupconv_dropin_golden(F):
+    """conv.h groupconv with host pointers on every golden single-layer case."""
+    g = np.load(os.path.join(GOLD, "groupconv_cases.npz"))
+    for m in json.loads(bytes(g["meta_json"]).decode()):
+        out = F.groupconv(g[m["name"] + "_x"], g[m["name"] + "_f"], m["groups"], m["pad"], m["stride"], m["fs"], m["act"])
+        close(out, g[m["name"] + "_out_v0"], m["name"])
+
+
+def test_net_api_single_frame(F, net, test_image):
+    """ffcnn.h path: net_load(cfg, weights, 0, 0) + net_input(test.bmp) + net_forward."""
+    bgr, w, h = test_image
+    gold = json.load(open(os.path.join(GOLD, "boxes.json")))["net_320x320_v0"]
+    net.set_input_image(bgr, w, h)
+    g = np.load(os.path.join(GOLD, "input_320.npz"))
+    assert np.array_equal(net.input.reshape(-1)[g["idx"]], g["samples"])
+    assert (net.n.s1, net.n.s2) == (640, 320)
+    for _ in range(2):                              # second call replays the captured graph
+        net.forward()
+        boxes_match(net.boxes, gold["boxes"], "net_forward")
+    assert net.layer_num == 131 and net.n.weight_size == 356576
+
+
+def test_cli_geometry_640x448(F, test_image):
+    """what the reference CLI does: net_load with the BMP size -> 640x448 (ffcnn.c:574,133-134)."""
+    bgr, w, h = test_image
+    gold = json.load(open(os.path.join(GOLD, "boxes.json")))["cli_640x448_v0"]
+    with F.Net(w=w, h=h) as n:
+        assert n.input_shape == (3, 448, 640)
+        n.set_input_image(bgr, w, h)
+        n.forward()
+        boxes_match(n.boxes, gold["boxes"], "cli geometry")
+
+
+def test_every_layer_keep_all(F, net, frames, oracle_runs):
+    """unfused executor, batch 4: every layer of every frame against the oracle."""
+    with net.executor(4, F.FFGPU.KEEP_ALL | F.FFGPU.NO_GRAPH) as ex:
+        ex.forward_host(frames)
+        for f in range(4):
+            for i, ref in oracle_runs[f]["acts"].items():
+                if net.layer(i).type == 4:          # dropout: alias
+                    continue
+                close(ex.read_layer(i, f), ref, "frame %d layer %d" % (f, i))
+
+
+def test_golden_layer_samples(F, net, frames):
+    """frame 0 against the reference's own per-layer samples (not via the oracle)."""
+    g = np.load(os.path.join(GOLD, "layers_320.npz"))
+    with net.executor(1, F.FFGPU.KEEP_ALL) as ex:
+        ex.forward_host(frames[:1])
+        for i in g["v0_layers"]:
+            a = ex.read_layer(int(i), 0).reshape(-1)
+            close(a[g["v0_L%d_idx" % i]], g["v0_L%d_samples" % i], "golden layer %d" % i)
+        hd = np.load(os.path.join(GOLD, "heads_320.npz"))
+        close(ex.read_layer(120, 0), hd["L120"], "head L120")
+        close(ex.read_layer(129, 0), hd["L129"], "head L129")
+
+
+@pytest.mark.parametrize("flags", [0, 4, 8, 12])
+def test_fused_graph_executor_boxes(F, net, frames, oracle_runs, flags):
+    """default (fused, graph) and the NO_GRAPH / NO_FUSE variants: candidates + boxes per frame."""
+    with net.executor(4, flags) as ex:
+        for rep in range(2):
+            ex.forward_host(frames)
+            dets = ex.read_dets()
+            for f in range(4):
+                want = oracle_runs[f]
+                assert dets[f]["ncand"] == len(want["cand"]) and dets[f]["overflow"] == 0
+                cand = ex.read_candidates(f)
+                boxes_match(cand, want["cand"], "cand frame %d" % f)
+                boxes_match(ex.boxes(f, dets), want["boxes"], "boxes frame %d" % f)
+        assert ex.kernel_count <= 140
+
+
+def test_compat_v6_executor(F, net, frames, orc):
+    """FFGPU_COMPAT_V6 reproduces conv-v6.c's 5x5 row omission (layers 116.. and 125..)."""
+    o = orc.Oracle()
+    o.input[...] = frames[0]
+    o.forward(1)
+    with net.executor(1, F.FFGPU.KEEP_ALL | F.FFGPU.COMPAT_V6) as ex:
+        ex.forward_host(frames[:1])
+        for i in (116, 118, 120, 125, 127, 129):
+            close(ex.read_layer(i, 0), o.layer_out(i), "compat layer %d" % i)
+    g = np.load(os.path.join(GOLD, "layers_320.npz"))
+    with net.executor(1, F.FFGPU.KEEP_ALL | F.FFGPU.COMPAT_V6) as ex:
+        ex.forward_host(frames[:1])
+        a = ex.read_layer(129, 0).reshape(-1)
+        close(a[g["v6_L129_idx"]], g["v6_L129_samples"], "golden v6 L129")
+    o.close()
+
+
+def test_scale_and_bgr_input(F, net, test_image, orc):
+    """device-side batched net_input (u8 BGR -> letterbox) + box rescale == reference net_input path."""
+    import torch
+    bgr, w, h = test_image
+    gold = json.load(open(os.path.join(GOLD, "boxes.json")))["net_320x320_v0"]
+    d = torch.from_numpy(np.stack([bgr, bgr[::-1].copy()])).cuda()        # frame 1: upside-down image
+    with net.executor(2) as ex:
+        ex.forward_bgr_dev(d.data_ptr(), w, h)
+        dets = ex.read_dets()
+        boxes_match(ex.boxes(0, dets), gold["boxes"], "bgr frame 0")
+        o = orc.Oracle()
+        o.set_input_image(np.ascontiguousarray(bgr[::-1]), w, h)
+        o.forward(0)
+        boxes_match(ex.boxes(1, dets), o.boxes, "bgr frame 1")
+        o.close()
+
+
+def test_forward_dev_torch_stream(F, net, frames, oracle_runs):
+    """device-resident input on a non-default torch stream (what bench.py does)."""
+    import torch
+    s = torch.cuda.Stream()
+    x = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    with net.executor(4) as ex:
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                ex.forward_dev(x.data_ptr(), s.cuda_stream)
+        s.synchronize()
+        dets = ex.read_dets()
+        for f in range(4):
+            boxes_match(ex.boxes(f, dets), oracle_runs[f]["boxes"], "frame %d" % f)
+
+
+def test_batch_sizes_and_arena(F, net, frames, oracle_runs):
+    sizes = {}
+    for b in (1, 2, 3):
+        with net.executor(b) as ex:
+            ex.forward_host(frames[:b])
+            dets = ex.read_dets()
+            for f in range(b):
+                boxes_match(ex.boxes(f, dets), oracle_runs[f]["boxes"], "batch %d frame %d" % (b, f))
+            sizes[b] = ex.arena_bytes
+    with net.executor(1, F.FFGPU.KEEP_ALL) as ex:
+        keep = ex.arena_bytes
+    assert sizes[1] < keep / 3          # liveness reuse: far smaller than one-buffer-per-layer
+    assert sizes[2] <= 2 * sizes[1] + 4096 * 131
+
+
+def test_missing_weights_and_bad_cfg(F):
+    assert F.net_load("/nonexistent.cfg", None) is None
+    with F.Net(weights="/nonexistent.weights") as n:      # tolerated (ffcnn.c:213-220): zero filters
+        assert not n.weights_host().any()
+        n.forward()
+        assert n.n.bbox_num == 0
