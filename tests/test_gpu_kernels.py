@@ -1,0 +1,134 @@
+"""Specialised conv kernels (dw3_stream, pw_mfma) against the generic kernel on the GPU and
+against the CPU oracle, over shapes that exercise every tail: odd heights, partial lane
+groups, batch > 1 (channel = plane / N), K padding, channel counts that do not fill a tile."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATOL, RTOL = 1e-3, 1e-3
+
+
+def make_filter(rng, fn, K):
+    k4 = (K + 3) & ~3
+    f = np.zeros((fn, k4 + 4), np.float32)
+    f[:, :K] = rng.uniform(-0.5, 0.5, (fn, K))
+    f[:, k4] = rng.uniform(0.5, 1.5, fn)
+    f[:, k4 + 1] = rng.uniform(-0.1, 0.1, fn)
+    return f
+
+
+def run_dev(capi, torch, x_cnhw, f, N, iw, ih, ic, groups, pad, stride, fs, fn, act, variant):
+    ow, oh = (iw + 2 * pad - fs) // stride + 1, (ih + 2 * pad - fs) // stride + 1
+    dx, df = torch.from_numpy(x_cnhw).cuda(), torch.from_numpy(f).cuda()
+    dy = torch.full((fn * N, oh, ow), float("nan"), device="cuda")
+    capi.groupconv_dev(dx.data_ptr(), df.data_ptr(), dy.data_ptr(), N, iw, ih, ic, groups, pad, stride, fs, fn, act,
+                       0, variant, None)
+    torch.cuda.synchronize()
+    return dy.cpu().numpy()
+
+
+def check(a, ref, what):
+    assert not np.isnan(a).any(), what + ": unwritten outputs"
+    err = np.abs(a - ref) - (ATOL + RTOL * np.abs(ref))
+    assert err.max() <= 0, "%s: max |d| %.3g" % (what, np.abs(a - ref).max())
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from ffcnn_amd import capi
+    capi.lib()
+    return capi, torch
+
+
+DW_SHAPES = [  # (C, N, H, W, act)
+    (8, 3, 160, 160, 2), (5, 2, 37, 80, 2), (3, 1, 2, 40, 0), (7, 2, 5, 64, 1), (2, 2, 19, 256, 2),
+    (3, 2, 33, 320, 2), (2, 1, 9, 512, 2), (4, 1, 320, 320, 2), (13, 1, 3, 48, 2), (1, 5, 41, 100, 2),
+]
+
+
+@pytest.mark.parametrize("shape", DW_SHAPES)
+@pytest.mark.parametrize("U,NT", [(4, 0), (2, 1)])
+def test_dw3_stream(env, orc, shape, U, NT, monkeypatch):
+    capi, torch = env
+    C, N, H, W, act = shape
+    monkeypatch.setenv("FFGPU_DW_U", str(U))
+    monkeypatch.setenv("FFGPU_DW_NT", str(NT))
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (C * N, H, W)).astype(np.float32)
+    f = make_filter(rng, C, 9)
+    assert capi.kernel_name(N, W, H, C, C, 1, 1, 3, C, capi.FFGPU.K_DW_STREAM) == "dw3_stream"
+    got = run_dev(capi, torch, x, f, N, W, H, C, C, 1, 1, 3, C, act, capi.FFGPU.K_DW_STREAM)
+    ref = run_dev(capi, torch, x, f, N, W, H, C, C, 1, 1, 3, C, act, capi.FFGPU.K_GENERIC)
+    check(got, ref, "dw3_stream %s vs generic" % (shape,))
+    if H * W * C * N <= 300000:       # oracle frame by frame (CNHW -> CHW per frame)
+        xf = x.reshape(C, N, H, W)
+        for n in range(N):
+            o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, C, 1, 1, 3, act)
+            check(got.reshape(C, N, H, W)[:, n], o, "dw3_stream %s frame %d vs oracle" % (shape, n))
+
+
+PW_SHAPES = [  # (ic, oc, N, H, W, act)
+    (8, 8, 2, 160, 160, 2), (8, 4, 1, 16, 16, 0), (4, 24, 3, 20, 20, 2), (24, 136, 2, 20, 20, 2),
+    (96, 255, 2, 10, 10, 0), (6, 7, 1, 6, 6, 2), (224, 48, 3, 10, 10, 0), (192, 96, 1, 10, 10, 2),
+    (256, 512, 2, 20, 20, 2), (16, 96, 1, 3, 4, 1), (120, 120, 1, 20, 20, 3),
+]
+
+
+@pytest.mark.parametrize("shape", PW_SHAPES)
+def test_pw_mfma(env, orc, shape):
+    capi, torch = env
+    ic, oc, N, H, W, act = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f = make_filter(rng, oc, ic)
+    assert capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc, capi.FFGPU.K_PW_MFMA) == "pw_mfma"
+    got = run_dev(capi, torch, x, f, N, W, H, ic, 1, 0, 1, 1, oc, act, capi.FFGPU.K_PW_MFMA)
+    ref = run_dev(capi, torch, x, f, N, W, H, ic, 1, 0, 1, 1, oc, act, capi.FFGPU.K_GENERIC)
+    check(got, ref, "pw_mfma %s vs generic" % (shape,))
+    if ic * oc * N * H * W <= 4e7:
+        xf = x.reshape(ic, N, H, W)
+        for n in range(N):
+            o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, 1, 0, 1, 1, act)
+            check(got.reshape(oc, N, H, W)[:, n], o, "pw_mfma %s frame %d vs oracle" % (shape, n))
+
+
+def test_unsupported_variant_fails_loudly(env):
+    capi, torch = env
+    x = torch.zeros((4, 7, 7), device="cuda")          # W % 4 != 0: the stream kernel must refuse
+    f = torch.zeros((4, 16), device="cuda")
+    y = torch.zeros((4, 7, 7), device="cuda")
+    with pytest.raises(RuntimeError, match="does not support"):
+        capi.groupconv_dev(x.data_ptr(), f.data_ptr(), y.data_ptr(), 1, 7, 7, 4, 4, 1, 1, 3, 4, 2, 0, capi.FFGPU.K_DW_STREAM)
+
+
+def test_full_size_properties(env):
+    """BASELINE config[1] size (320x320x64, batch 64): linearity + shift properties instead of an oracle run."""
+    capi, torch = env
+    C, N, H, W = 64, 8, 320, 320          # 8 frames here; bench.py runs the 64-frame case
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand((C * N, H, W), device="cuda", generator=g) - 0.5
+    f = torch.zeros((C, 16), device="cuda")
+    f[:, :9] = torch.rand((C, 9), device="cuda", generator=g) - 0.5
+    f[:, 12] = 1.0
+    y1, y2, y3 = (torch.empty_like(x) for _ in range(3))
+
+    def run(inp, out):
+        capi.groupconv_dev(inp.data_ptr(), f.data_ptr(), out.data_ptr(), N, W, H, C, C, 1, 1, 3, C, 0, 0, capi.FFGPU.K_DW_STREAM)
+    run(x, y1)
+    x2 = 2.0 * x
+    run(x2, y2)
+    torch.cuda.synchronize()
+    assert torch.allclose(y2, 2 * y1, rtol=1e-5, atol=1e-5)            # linear layer, bias 0
+    # a plane made of one impulse reproduces the flipped 3x3 taps around it (checks column/row neighbours,
+    # including across the lane-63/lane-0 seam at column 255/256)
+    imp = torch.zeros_like(x)
+    imp[:, 100, 255] = 1.0
+    imp[:, 200, 256] = 1.0
+    run(imp, y3)
+    torch.cuda.synchronize()
+    taps = f[:, :9].reshape(C, 3, 3).repeat_interleave(N, dim=0)
+    for (r, c) in ((100, 255), (200, 256)):
+        patch = y3[:, r - 1:r + 2, c - 1:c + 2]
+        assert torch.allclose(patch, torch.flip(taps, dims=(1, 2)), atol=1e-6), (r, c)
