@@ -63,7 +63,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_create", "ffgpu_exec_destroy", "ffgpu_exec_batch", "ffgpu_exec_arena_bytes",
            "ffgpu_exec_kernel_count", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
            "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
-           "ffgpu_exec_profile", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev"]
+           "ffgpu_exec_profile", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_membench"]
 
 
 def library_path():
@@ -126,6 +126,8 @@ def lib():
     L.ffgpu_groupconv_kernel_name.argtypes = [i] * 10
     L.ffgpu_groupconv_time_dev.restype = C.c_float
     L.ffgpu_groupconv_time_dev.argtypes = [vp, vp, vp] + [i] * 17 + [vp]
+    L.ffgpu_membench.restype = C.c_float
+    L.ffgpu_membench.argtypes = [vp, vp, sz, i, i, i, vp]
     _lib = L
     return L
 

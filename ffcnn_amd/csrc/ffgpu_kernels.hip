@@ -351,3 +351,82 @@ int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, const int *ncand, ff
     LAUNCH_OK("nms");
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// HBM stream calibration (ffgpu_membench)
+typedef float mb4 __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ void __launch_bounds__(256) k_membench(mb4 *dst, const mb4 *src, long n4)
+{
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
+    if (MODE == 0) for (long i = gid; i < n4; i += gsz) dst[i] = src[i];
+    if (MODE == 1) for (long i = gid; i < n4; i += gsz) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    if (MODE == 2) {
+        mb4 a = { 0.f, 0.f, 0.f, 0.f };
+        for (long i = gid; i < n4; i += gsz) a += src[i];
+        if (a.x + a.y + a.z + a.w == 12345.678f) dst[gid] = a;      // keep the loads alive
+    }
+    if (MODE == 3) { const mb4 v = { 1.f, 2.f, 3.f, 4.f }; for (long i = gid; i < n4; i += gsz) dst[i] = v; }
+    if (MODE == 5 || MODE == 6 || MODE == 7) {
+        // MODE 5: every WAVE owns one contiguous span and walks it with 4 x 1 KiB pieces in flight
+        // MODE 6: every BLOCK owns one contiguous span; its waves interleave at 1 KiB granularity
+        // MODE 7: as 5 with non-temporal loads and stores
+        const int lane = threadIdx.x & 63;
+        const long nw = (long)gridDim.x * (blockDim.x >> 6), w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        long b, e, step;
+        if (MODE == 6) {
+            const long per = ((n4 + gridDim.x - 1) / gridDim.x + 255) & ~255L;
+            b = blockIdx.x * per + (threadIdx.x >> 6) * 64; e = min(b - (threadIdx.x >> 6) * 64 + per, n4); step = blockDim.x;
+        } else {
+            const long per = ((n4 + nw - 1) / nw + 63) & ~63L;
+            b = w * per; e = min(b + per, n4); step = 64;
+        }
+        long i = b + lane;
+        for (; i + 3 * step < e; i += 4 * step) {
+            mb4 a0, a1, a2, a3;
+            if (MODE == 7) { a0 = __builtin_nontemporal_load(src + i); a1 = __builtin_nontemporal_load(src + i + step);
+                             a2 = __builtin_nontemporal_load(src + i + 2 * step); a3 = __builtin_nontemporal_load(src + i + 3 * step); }
+            else { a0 = src[i]; a1 = src[i + step]; a2 = src[i + 2 * step]; a3 = src[i + 3 * step]; }
+            if (MODE == 7) { __builtin_nontemporal_store(a0, dst + i); __builtin_nontemporal_store(a1, dst + i + step);
+                             __builtin_nontemporal_store(a2, dst + i + 2 * step); __builtin_nontemporal_store(a3, dst + i + 3 * step); }
+            else { dst[i] = a0; dst[i + step] = a1; dst[i + 2 * step] = a2; dst[i + 3 * step] = a3; }
+        }
+        for (; i < e; i += step) dst[i] = src[i];
+    }
+    if (MODE == 4) {
+        long i = gid;
+        for (; i + 3 * gsz < n4; i += 4 * gsz) {
+            const mb4 a = src[i], b = src[i + gsz], c = src[i + 2 * gsz], d = src[i + 3 * gsz];
+            dst[i] = a; dst[i + gsz] = b; dst[i + 2 * gsz] = c; dst[i + 3 * gsz] = d;
+        }
+        for (; i < n4; i += gsz) dst[i] = src[i];
+    }
+}
+
+extern "C" float ffgpu_membench(void *d_dst, const void *d_src, size_t bytes, int mode, int blocks, int iters, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const long n4 = (long)(bytes / 16);
+    if (!d_dst || !d_src || n4 < 1 || blocks < 1 || iters < 1) { ffgpu_set_error("membench: bad arguments"); return -1.f; }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
+    for (int it = 0; it < iters + 2; it++) {
+        if (it == 2) (void)hipEventRecord(e0, s);
+        switch (mode) {
+        case 0: hipLaunchKernelGGL(k_membench<0>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
+        case 1: hipLaunchKernelGGL(k_membench<1>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
+        case 2: hipLaunchKernelGGL(k_membench<2>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
+        case 3: hipLaunchKernelGGL(k_membench<3>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
+        case 5: hipLaunchKernelGGL(k_membench<5>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
+        case 6: hipLaunchKernelGGL(k_membench<6>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
+        case 7: hipLaunchKernelGGL(k_membench<7>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
+        default: hipLaunchKernelGGL(k_membench<4>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
+        }
+    }
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) { ffgpu_set_error("membench: %s", hipGetErrorString(hipGetLastError())); return -1.f; }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms * 1000.f / iters;
+}

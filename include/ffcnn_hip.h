@@ -137,6 +137,14 @@ float ffgpu_groupconv_time_dev(const float *d_in, const float *d_filt, float *d_
                                int fs, int fn, int ow, int oh, int oc, int act,
                                int flags, int variant, int warmup, int iters, void *stream);
 
+/* ---- diagnostics -------------------------------------------------------- */
+/* HBM stream calibration on this GPU: mean microseconds per pass over `bytes`
+ * (16-byte lanes, grid-stride, `blocks` workgroups of 256).  mode 0: copy,
+ * 1: copy with non-temporal loads+stores, 2: read only, 3: write only,
+ * 4: copy, 4 independent 16-byte loads in flight per lane.  Used by bench.py
+ * to report the measured copy ceiling next to the 8 TB/s spec. */
+float ffgpu_membench(void *d_dst, const void *d_src, size_t bytes, int mode, int blocks, int iters, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
