@@ -18,7 +18,7 @@ class FFGPU:
     MAX_DET = 128
     MAX_CAND = 1024
     KEEP_ALL, COMPAT_V6, NO_GRAPH, NO_FUSE = 1, 2, 4, 8
-    K_AUTO, K_GENERIC, K_DW_STREAM, K_DW_LDS, K_PW_MFMA, K_PW_GEMM, K_PW_VALU = range(7)
+    K_AUTO, K_GENERIC, K_DW_STREAM, K_DW_LDS, K_PW_MFMA, K_PW_GEMM, K_PW_VALU, K_DENSE_SMALL = range(8)
 
 
 class LAYER(C.Structure):            # include/ffcnn.h (120 bytes)
@@ -63,7 +63,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_create", "ffgpu_exec_destroy", "ffgpu_exec_batch", "ffgpu_exec_arena_bytes",
            "ffgpu_exec_kernel_count", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
            "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
-           "ffgpu_exec_profile", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_membench"]
+           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_membench"]
 
 
 def library_path():
@@ -121,6 +121,7 @@ def lib():
     L.ffgpu_exec_read_dets.argtypes = [vp, vp, i]
     L.ffgpu_exec_read_layer.argtypes = [vp, i, i, f32p, sz]
     L.ffgpu_exec_profile.argtypes = [vp, vp, f32p]
+    L.ffgpu_exec_profile_steps.argtypes = [vp, vp, C.POINTER(i), f32p, i]
     L.ffgpu_groupconv_dev.argtypes = [vp, vp, vp] + [i] * 15 + [vp]
     L.ffgpu_groupconv_kernel_name.restype = C.c_char_p
     L.ffgpu_groupconv_kernel_name.argtypes = [i] * 10
@@ -333,6 +334,12 @@ class Executor:
         out = np.zeros(FFGPU.MAX_CAND, BOX_DTYPE)
         n = _check(lib().ffgpu_exec_read_layer(self.h, -2, frame, out.ctypes.data_as(f32p), out.size * 6), "read candidates")
         return out[:n].copy()
+
+    def profile_steps(self, dev_ptr):
+        cap = 512
+        lay, us = (C.c_int * cap)(), (C.c_float * cap)()
+        n = _check(lib().ffgpu_exec_profile_steps(self.h, dev_ptr, lay, us, cap), "ffgpu_exec_profile_steps")
+        return [(lay[k], us[k]) for k in range(n)]
 
     def profile(self, dev_ptr):
         us = (C.c_float * 8)()

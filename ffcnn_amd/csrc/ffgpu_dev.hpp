@@ -35,6 +35,16 @@ struct ConvDesc {
 
 static inline int conv_k4(const ConvDesc &d) { return (d.fs * d.fs * (d.ic / d.groups) + 3) & ~3; }
 
+// Fused 1x1 expand -> depthwise 3x3 -> 1x1 project [+ residual] on CNHW tensors (ffgpu_irb.inc)
+struct IrbDesc {
+    const float *in; float *out; const float *residual;
+    const float *w1, *wd, *w2;
+    int N, H, W, OH, OW, ic, ec, oc, stride;
+    int act1, actd, act2, res_act;
+};
+bool ffgpu_irb_supported(const IrbDesc &d);
+int  ffgpu_launch_irb(const IrbDesc &d, hipStream_t s);
+
 // kernels.hip
 int         ffgpu_launch_conv(const ConvDesc &d, int variant, hipStream_t s);
 const char *ffgpu_conv_kernel_name(const ConvDesc &d, int variant);

@@ -58,7 +58,7 @@ extern "C" int ffgpu_set_device(int ordinal)
 }
 
 // --------------------------------------------------------------------------
-enum StepKind { S_CONV, S_POOL, S_UPSAMPLE, S_ADD, S_COPY, S_YOLO, S_NMS, S_CLEAR, S_TOCNHW };
+enum StepKind { S_CONV, S_POOL, S_UPSAMPLE, S_ADD, S_COPY, S_YOLO, S_NMS, S_CLEAR, S_TOCNHW, S_IRB };
 
 struct Step {
     StepKind kind;
@@ -71,6 +71,7 @@ struct Step {
     long     n;              // element count (ADD/COPY) or planes
     int      w, h, c, fs, stride, flag;
     YoloHead head;
+    IrbDesc  irb;            // S_IRB: fused expand -> depthwise -> project [+ shortcut]
 };
 
 struct Tensor {
@@ -97,7 +98,8 @@ struct ffgpu_exec {
     int  in_c = 0, in_h = 0, in_w = 0;
     std::vector<Step>   steps;
     std::vector<Tensor> tensors;       // index = layer id
-    std::vector<int>    canon;         // layer id -> tensor id holding its output (-1: the batch input, -2: none)
+    std::vector<int>    canon;         // layer id -> tensor id holding its output (-1: the batch input, -2: none, -3: fused away)
+    std::vector<char>   readable;      // layer's own output value exists in memory after a forward
     float *arena = nullptr;
     size_t arena_floats = 0;
     float *d_input = nullptr;          // own staging buffer for host / bgr entry points
@@ -128,7 +130,7 @@ static int plan(ffgpu_exec *ex)
     NET *net = ex->net;
     const int L = net->layer_num, N = ex->N;
     const bool keep_all = ex->flags & FFGPU_KEEP_ALL;
-    const bool fuse = !keep_all && !(ex->flags & FFGPU_NO_FUSE);
+    const bool fuse = !(ex->flags & FFGPU_NO_FUSE);
     const LAYER *ll = net->layer_list;
     std::vector<Tensor> &T = ex->tensors;
     std::vector<int> &canon = ex->canon;
@@ -166,7 +168,37 @@ static int plan(ffgpu_exec *ex)
             if (chain_private) { fused_into[p] = i; for (int q = p; q < i; q++) canon[q] = i; }
         }
     }
+    // pass 1b: 1x1 expand -> depthwise 3x3 -> 1x1 project triples become ONE fused kernel (ffgpu_irb.inc);
+    // the two expanded tensors are never materialised
+    std::vector<int> irb_tail(L, -1);           // layer p+2 -> p
+    static const bool no_irb = getenv("FFGPU_NO_IRB") && atoi(getenv("FFGPU_NO_IRB"));
+    if (fuse && !no_irb) {
+        for (int p0 = 0; p0 + 2 < L; p0++) {
+            const LAYER &a = ll[p0], &b = ll[p0 + 1], &c = ll[p0 + 2];
+            if (a.type != LAYER_TYPE_CONV || b.type != LAYER_TYPE_CONV || c.type != LAYER_TYPE_CONV) continue;
+            const bool pw_a = a.fs == 1 && a.stride == 1 && a.pad == 0 && a.groups == 1;
+            const bool dw_b = b.fs == 3 && b.pad == 1 && (b.stride == 1 || b.stride == 2) && b.groups == b.c && b.fn == b.c;
+            const bool pw_c = c.fs == 1 && c.stride == 1 && c.pad == 0 && c.groups == 1;
+            if (!pw_a || !dw_b || !pw_c || nuses[p0] != 1 || nuses[p0 + 1] != 1 || src_tensor(p0 - 1) < 0) continue;
+            if (canon[p0] != p0 || canon[p0 + 1] != p0 + 1) continue;
+            IrbDesc d{};
+            d.N = N; d.H = a.h; d.W = a.w; d.OH = ll[p0 + 3].h; d.OW = ll[p0 + 3].w;
+            d.ic = a.c; d.ec = a.fn; d.oc = c.fn; d.stride = b.stride;
+            d.act1 = a.activation; d.actd = b.activation; d.act2 = c.activation;
+            d.res_act = fused_into[p0 + 2] >= 0 ? ll[fused_into[p0 + 2]].activation : 0;
+            if (!ffgpu_irb_supported(d)) continue;
+            irb_tail[p0 + 2] = p0;
+            canon[p0] = canon[p0 + 1] = -3;
+            p0 += 2;
+        }
+    }
     for (int i = 0; i < L; i++) if (canon[i] == i) { T[i].used = true; T[i].size = out_floats(i); }
+    ex->readable.assign(L, 0);
+    for (int i = 0; i < L; i++) {
+        if (canon[i] == i) ex->readable[i] = 1;
+        else if (ll[i].type == LAYER_TYPE_DROPOUT && i > 0 && canon[i] >= 0 && canon[i] == canon[i - 1]) ex->readable[i] = ex->readable[i - 1];
+        else if (ll[i].type == LAYER_TYPE_ROUTE && ll[i].depend_num == 1 && canon[i] >= 0) ex->readable[i] = ex->readable[ll[i].depend_list[0]];
+    }
 
     // pass 2: concat-in-place for multi-source routes
     std::vector<char> route_inplace(L, 0);
@@ -194,6 +226,8 @@ static int plan(ffgpu_exec *ex)
         if (canon[i] >= 0 && !(ll[i].type == LAYER_TYPE_ROUTE && canon[i] != i)) touch(canon[i], i);     // written at i
         if (ll[i].type != LAYER_TYPE_ROUTE) touch(src_tensor(i - 1), i);                                  // chain input read at i
         for (int k = 0; k < ll[i].depend_num; k++) touch(src_tensor(ll[i].depend_list[k]), i);
+        if (irb_tail[i] >= 0) touch(src_tensor(irb_tail[i] - 1), i);
+        if (irb_tail[i] >= 0 && fused_into[i] >= 0) touch(src_tensor(ll[fused_into[i]].depend_list[0]), i);
     }
     for (int t = 0; t < L; t++) {
         if (!T[t].used || T[t].parent < 0) continue;
@@ -246,6 +280,28 @@ static int plan(ffgpu_exec *ex)
         bool from_input = false;
         switch (a.type) {
         case LAYER_TYPE_CONV: {
+            if (canon[i] == -3) break;                              // expanded tensors of a fused block
+            if (irb_tail[i] >= 0) {
+                const int p0 = irb_tail[i];
+                const LAYER &la = ll[p0], &lb = ll[p0 + 1], &lc = ll[p0 + 2];
+                IrbDesc &d = st.irb;
+                st.kind = S_IRB;
+                d.in = tensor_ptr(ex, src_tensor(p0 - 1));
+                d.out = tensor_ptr(ex, canon[i]);
+                d.w1 = ex->dev->d_weights + (la.filter - net->weight_buf);
+                d.wd = ex->dev->d_weights + (lb.filter - net->weight_buf);
+                d.w2 = ex->dev->d_weights + (lc.filter - net->weight_buf);
+                d.N = N; d.H = la.h; d.W = la.w; d.OH = b.h; d.OW = b.w;
+                d.ic = la.c; d.ec = la.fn; d.oc = lc.fn; d.stride = lb.stride;
+                d.act1 = la.activation; d.actd = lb.activation; d.act2 = lc.activation;
+                if (fused_into[i] >= 0) {
+                    const LAYER &sc = ll[fused_into[i]];
+                    d.residual = tensor_ptr(ex, src_tensor(sc.depend_list[0]));
+                    d.res_act = sc.activation;
+                }
+                S.push_back(st);
+                break;
+            }
             ConvDesc &d = st.conv;
             st.kind = S_CONV;
             d.in = in_ptr(i, &from_input);
@@ -353,6 +409,8 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
                                          d_frames + (long)c * plane, (size_t)st.c * plane * sizeof(float),
                                          plane * sizeof(float), ex->N, hipMemcpyDeviceToDevice, s));
         return 0; }
+    case S_IRB:
+        return ffgpu_launch_irb(st.irb, s);
     case S_YOLO:
         return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand, s);
     case S_NMS:
@@ -534,7 +592,10 @@ extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float
         return cnt;
     }
     if (!(ex->flags & FFGPU_KEEP_ALL)) { ffgpu_set_error("read_layer needs an FFGPU_KEEP_ALL executor"); return -1; }
-    if (layer < 0 || layer >= ex->net->layer_num || ex->canon[layer] < 0) { ffgpu_set_error("read_layer: layer %d has no tensor", layer); return -1; }
+    if (layer < 0 || layer >= ex->net->layer_num || ex->canon[layer] < 0 || !ex->readable[layer]) {
+        ffgpu_set_error("read_layer: layer %d is not materialised by this executor (fused away or no tensor)", layer);
+        return -1;
+    }
     const LAYER &o = ex->net->layer_list[layer + 1];
     const size_t plane = (size_t)o.w * o.h;
     if (plane * o.c > cap_floats) { ffgpu_set_error("read_layer: buffer too small"); return -1; }
@@ -567,6 +628,35 @@ extern "C" int ffgpu_exec_profile(ffgpu_exec *ex, const float *d_frames, float u
     for (auto &e : ev) (void)hipEventDestroy(e);
     ex->last_stream = s;
     return 0;
+}
+
+extern "C" int ffgpu_exec_profile_steps(ffgpu_exec *ex, const float *d_frames, int *layer_of, float *us, int cap)
+{
+    if (!ex || !d_frames || !layer_of || !us) { ffgpu_set_error("profile_steps: NULL argument"); return -1; }
+    hipStream_t s = ex->own_stream;
+    const int n = (int)std::min<size_t>(ex->steps.size(), (size_t)cap);
+    std::vector<hipEvent_t> ev(ex->steps.size() + 1);
+    for (auto &e : ev) FFGPU_CHECK(hipEventCreate(&e));
+    std::vector<float> acc(ex->steps.size(), 0.f);
+    const int reps = 5;
+    if (issue_all(ex, d_frames, s)) return -1;
+    for (int r = 0; r < reps; r++) {
+        FFGPU_CHECK(hipEventRecord(ev[0], s));
+        for (size_t i = 0; i < ex->steps.size(); i++) {
+            if (issue_step(ex, ex->steps[i], d_frames, s)) return -1;
+            FFGPU_CHECK(hipEventRecord(ev[i + 1], s));
+        }
+        FFGPU_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < ex->steps.size(); i++) {
+            float ms = 0.f;
+            FFGPU_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            acc[i] += ms * 1000.f / reps;
+        }
+    }
+    for (int i = 0; i < n; i++) { layer_of[i] = ex->steps[i].layer; us[i] = acc[i]; }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    ex->last_stream = s;
+    return n;
 }
 
 // -------------------------------------------------------------------------- C-ABI: net device state

@@ -43,7 +43,8 @@ typedef struct {
 typedef struct ffgpu_exec ffgpu_exec;     /* a planned executor: one NET x one batch size */
 
 /* executor flags */
-#define FFGPU_KEEP_ALL   1    /* one buffer per layer (no arena reuse): per-layer read-back  */
+#define FFGPU_KEEP_ALL   1    /* no arena reuse: every tensor that is materialised can be read */
+                              /* back (combine with FFGPU_NO_FUSE for one tensor per layer)    */
 #define FFGPU_COMPAT_V6  2    /* reproduce conv-v6.c:422-441 (5x5 depthwise row oh-2 defect) */
 #define FFGPU_NO_GRAPH   4    /* launch kernels eagerly instead of replaying a HIP graph     */
 #define FFGPU_NO_FUSE    8    /* one kernel per reference layer (no cross-layer fusion)      */
@@ -105,6 +106,11 @@ int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float *host_out,
  * ffcnn.c:33,494-510).  Runs one eager forward with hipEvents around each step. */
 int ffgpu_exec_profile(ffgpu_exec *ex, const float *d_frames, float us_by_kind[LAYER_TYPE_TOTOAL]);
 
+/* Per-launch breakdown of one eager forward: for step i, layer_of[i] is the
+ * reference layer index it implements (-1: executor bookkeeping), us[i] its
+ * device time.  Returns the number of steps (<= cap) or a negative error. */
+int ffgpu_exec_profile_steps(ffgpu_exec *ex, const float *d_frames, int *layer_of, float *us, int cap);
+
 /* ---- single operators on device tensors (CNHW, any batch) --------------- */
 /* Counterpart of groupconv (conv.h:4-7) without the host round trip.  d_in is
  * ic*batch planes of ih*iw, d_out oc*batch planes of oh*ow; d_filt as conv.h.
@@ -122,7 +128,8 @@ enum {
     FFGPU_K_DW_LDS = 3,       /* depthwise 3x3/5x5, s1/s2: whole planes staged in LDS     */
     FFGPU_K_PW_MFMA = 4,      /* 1x1: fp32 MFMA 16x16x4, streaming (bandwidth-bound)      */
     FFGPU_K_PW_GEMM = 5,      /* 1x1: LDS-tiled fp32 MFMA 32x32x2 GEMM (compute-bound)    */
-    FFGPU_K_PW_VALU = 6       /* 1x1: plain VALU FMA (baseline / tiny channel counts)     */
+    FFGPU_K_PW_VALU = 6,      /* 1x1: plain VALU FMA (baseline / tiny channel counts)     */
+    FFGPU_K_DENSE_SMALL = 7   /* dense 3x3/5x5 with <= 8 input channels (the first layer)   */
 };
 
 /* name of the kernel `variant` resolves to for this shape (for logs/benches) */

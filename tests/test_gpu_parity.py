@@ -109,7 +109,7 @@ def test_cli_geometry_640x448(F, test_image):
 
 def test_every_layer_keep_all(F, net, frames, oracle_runs):
     """unfused executor, batch 4: every layer of every frame against the oracle."""
-    with net.executor(4, F.FFGPU.KEEP_ALL | F.FFGPU.NO_GRAPH) as ex:
+    with net.executor(4, F.FFGPU.KEEP_ALL | F.FFGPU.NO_FUSE | F.FFGPU.NO_GRAPH) as ex:
         ex.forward_host(frames)
         for f in range(4):
             for i, ref in oracle_runs[f]["acts"].items():
@@ -118,10 +118,32 @@ def test_every_layer_keep_all(F, net, frames, oracle_runs):
                 close(ex.read_layer(i, f), ref, "frame %d layer %d" % (f, i))
 
 
+def test_fused_executor_materialised_layers(F, net, frames, oracle_runs):
+    """fused executor (IRB blocks, shortcut-in-epilogue, concat in place), no arena reuse: every tensor
+    that still exists must equal the oracle's activation of that layer; the fused-away ones must refuse."""
+    with net.executor(4, F.FFGPU.KEEP_ALL) as ex:
+        ex.forward_host(frames)
+        seen, gone = 0, 0
+        for i, ref in oracle_runs[0]["acts"].items():
+            if net.layer(i).type == 4:
+                continue
+            try:
+                a = ex.read_layer(i, 0)
+            except RuntimeError as e:
+                assert "not materialised" in str(e)
+                gone += 1
+                continue
+            seen += 1
+            for f in range(4):
+                close(ex.read_layer(i, f), oracle_runs[f]["acts"][i], "fused: frame %d layer %d" % (f, i))
+        assert seen >= 40 and gone >= 40, (seen, gone)      # 20 blocks x (2 expanded tensors + projection absorbed by the shortcut)
+        assert ex.kernel_count <= 60
+
+
 def test_golden_layer_samples(F, net, frames):
     """frame 0 against the reference's own per-layer samples (not via the oracle)."""
     g = np.load(os.path.join(GOLD, "layers_320.npz"))
-    with net.executor(1, F.FFGPU.KEEP_ALL) as ex:
+    with net.executor(1, F.FFGPU.KEEP_ALL | F.FFGPU.NO_FUSE) as ex:
         ex.forward_host(frames[:1])
         for i in g["v0_layers"]:
             a = ex.read_layer(int(i), 0).reshape(-1)
@@ -206,7 +228,7 @@ def test_batch_sizes_and_arena(F, net, frames, oracle_runs):
             for f in range(b):
                 boxes_match(ex.boxes(f, dets), oracle_runs[f]["boxes"], "batch %d frame %d" % (b, f))
             sizes[b] = ex.arena_bytes
-    with net.executor(1, F.FFGPU.KEEP_ALL) as ex:
+    with net.executor(1, F.FFGPU.KEEP_ALL | F.FFGPU.NO_FUSE) as ex:
         keep = ex.arena_bytes
     assert sizes[1] < keep / 3          # liveness reuse: far smaller than one-buffer-per-layer
     assert sizes[2] <= 2 * sizes[1] + 4096 * 131
