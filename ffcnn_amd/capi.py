@@ -63,7 +63,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_create", "ffgpu_exec_destroy", "ffgpu_exec_batch", "ffgpu_exec_arena_bytes",
            "ffgpu_exec_kernel_count", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
            "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
-           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_membench"]
+           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_membench", "ffgpu_irb_dev"]
 
 
 def library_path():
@@ -127,6 +127,8 @@ def lib():
     L.ffgpu_groupconv_kernel_name.argtypes = [i] * 10
     L.ffgpu_groupconv_time_dev.restype = C.c_float
     L.ffgpu_groupconv_time_dev.argtypes = [vp, vp, vp] + [i] * 17 + [vp]
+    L.ffgpu_irb_dev.restype = C.c_float
+    L.ffgpu_irb_dev.argtypes = [vp] * 6 + [i] * 13 + [vp]
     L.ffgpu_membench.restype = C.c_float
     L.ffgpu_membench.argtypes = [vp, vp, sz, i, i, i, vp]
     _lib = L
@@ -365,3 +367,13 @@ def groupconv_time_dev(d_in, d_filt, d_out, batch, iw, ih, ic, groups, pad, stri
 
 def kernel_name(batch, iw, ih, ic, groups, pad, stride, fs, fn, variant=0):
     return lib().ffgpu_groupconv_kernel_name(batch, iw, ih, ic, groups, pad, stride, fs, fn, variant).decode()
+
+
+def irb_dev(d_in, d_w1, d_wd, d_w2, d_res, d_out, batch, iw, ih, ic, ec, oc, stride, act1=2, actd=2, act2=0, res_act=0,
+            warmup=0, iters=0, stream=None):
+    """fused expand -> dw3x3 -> project [+ residual]; returns us per launch when iters > 0"""
+    us = lib().ffgpu_irb_dev(d_in, d_w1, d_wd, d_w2, d_res, d_out, batch, iw, ih, ic, ec, oc, stride, act1, actd, act2, res_act,
+                             warmup, iters, stream)
+    if us < 0:
+        raise RuntimeError("ffgpu_irb_dev failed: %s" % last_error())
+    return us

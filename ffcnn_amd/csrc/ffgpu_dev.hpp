@@ -41,9 +41,12 @@ struct IrbDesc {
     const float *w1, *wd, *w2;
     int N, H, W, OH, OW, ic, ec, oc, stride;
     int act1, actd, act2, res_act;
+    const float *pk;          // packed constants (ffgpu_irb_pack_floats floats, filled by ffgpu_irb_pack)
 };
-bool ffgpu_irb_supported(const IrbDesc &d);
-int  ffgpu_launch_irb(const IrbDesc &d, hipStream_t s);
+bool   ffgpu_irb_supported(const IrbDesc &d);
+size_t ffgpu_irb_pack_floats(const IrbDesc &d);
+int    ffgpu_irb_pack(const IrbDesc &d, float *pk, hipStream_t s);
+int    ffgpu_launch_irb(const IrbDesc &d, hipStream_t s);
 
 // kernels.hip
 int         ffgpu_launch_conv(const ConvDesc &d, int variant, hipStream_t s);

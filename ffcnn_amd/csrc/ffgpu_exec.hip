@@ -85,6 +85,7 @@ struct Tensor {
 
 struct ffgpu_netdev {
     NET   *net = nullptr;
+    std::vector<ffgpu_exec *> execs;   // executors holding packings derived from d_weights
     float *d_weights = nullptr;
     size_t weight_bytes = 0;
     int    device = 0;
@@ -103,6 +104,7 @@ struct ffgpu_exec {
     float *arena = nullptr;
     size_t arena_floats = 0;
     float *d_input = nullptr;          // own staging buffer for host / bgr entry points
+    float *d_pack = nullptr;           // packed constants of the fused blocks (derived from the weights)
     BBOX  *d_cand = nullptr;
     int   *d_cand_key = nullptr, *d_ncand = nullptr;
     ffgpu_frame_dets *d_dets = nullptr;
@@ -186,7 +188,8 @@ static int plan(ffgpu_exec *ex)
             d.ic = a.c; d.ec = a.fn; d.oc = c.fn; d.stride = b.stride;
             d.act1 = a.activation; d.actd = b.activation; d.act2 = c.activation;
             d.res_act = fused_into[p0 + 2] >= 0 ? ll[fused_into[p0 + 2]].activation : 0;
-            if (!ffgpu_irb_supported(d)) continue;
+            static const int min_ec = getenv("FFGPU_IRB_MIN_EC") ? atoi(getenv("FFGPU_IRB_MIN_EC")) : 24;
+            if (d.ec < min_ec || !ffgpu_irb_supported(d)) continue;   // thin blocks: three streaming kernels are faster (profiles/)
             irb_tail[p0 + 2] = p0;
             canon[p0] = canon[p0 + 1] = -3;
             p0 += 2;
@@ -375,10 +378,26 @@ static int plan(ffgpu_exec *ex)
         default: break;                                             // dropout
         }
     }
+    {   // constants of the fused blocks, packed once into their LDS image
+        size_t tot = 0;
+        for (Step &st : S) if (st.kind == S_IRB) tot += ffgpu_irb_pack_floats(st.irb);
+        if (tot) {
+            if (hipMalloc(&ex->d_pack, tot * sizeof(float)) != hipSuccess) { ffgpu_set_error("hipMalloc(pack) failed"); return -1; }
+            size_t off = 0;
+            for (Step &st : S) if (st.kind == S_IRB) { st.irb.pk = ex->d_pack + off; off += ffgpu_irb_pack_floats(st.irb); }
+        }
+    }
     if (bad_chain) { ffgpu_set_error("a layer consumes the (non-existent) output of a yolo head"); return -1; }
     { Step nm{}; nm.kind = S_NMS; nm.layer = -1; nm.ltype = LAYER_TYPE_YOLO; S.push_back(nm); }
     ex->kernel_count = (int)S.size();
     (void)nheads;
+    return 0;
+}
+
+static int repack(ffgpu_exec *ex, hipStream_t s)
+{
+    for (const Step &st : ex->steps)
+        if (st.kind == S_IRB && ffgpu_irb_pack(st.irb, const_cast<float *>(st.irb.pk), s)) return -1;
     return 0;
 }
 
@@ -487,8 +506,9 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
            && hipMalloc(&ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess
            && hipMemset(ex->d_dets, 0, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess;
     if (!ok) { ffgpu_set_error("executor buffers: %s", hipGetErrorString(hipGetLastError())); ffgpu_exec_destroy(ex); return nullptr; }
-    if (plan(ex) != 0) { ffgpu_exec_destroy(ex); return nullptr; }
+    if (plan(ex) != 0 || repack(ex, ex->own_stream) != 0 || hipStreamSynchronize(ex->own_stream) != hipSuccess) { ffgpu_exec_destroy(ex); return nullptr; }
     ex->last_stream = ex->own_stream;
+    dev->execs.push_back(ex);
     return ex;
 }
 
@@ -496,9 +516,10 @@ extern "C" void ffgpu_exec_destroy(ffgpu_exec *ex)
 {
     if (!ex) return;
     if (ex->last_stream) (void)hipStreamSynchronize(ex->last_stream);
+    if (ex->dev) ex->dev->execs.erase(std::remove(ex->dev->execs.begin(), ex->dev->execs.end(), ex), ex->dev->execs.end());
     for (auto &g : ex->graphs) (void)hipGraphExecDestroy(g.second);
     for (const Step &st : ex->steps) if (st.kind == S_TOCNHW) (void)hipFree(st.out);
-    (void)hipFree(ex->arena); (void)hipFree(ex->d_input); (void)hipFree(ex->d_cand);
+    (void)hipFree(ex->arena); (void)hipFree(ex->d_input); (void)hipFree(ex->d_pack); (void)hipFree(ex->d_cand);
     (void)hipFree(ex->d_cand_key); (void)hipFree(ex->d_ncand); (void)hipFree(ex->d_dets);
     if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
     delete ex;
@@ -723,7 +744,9 @@ extern "C" int ffgpu_net_weights_commit(NET *net, void *stream)
 {
     ffgpu_netdev *dev = netdev_of(net);
     if (!dev) return -1;
-    (void)stream;       // kernels read the filter rows in place: nothing derived to refresh yet
+    for (ffgpu_exec *ex : dev->execs)           // fused blocks keep their constants in a packed LDS image
+        if (repack(ex, stream ? (hipStream_t)stream : ex->own_stream)) return -1;
+    if (!stream) for (ffgpu_exec *ex : dev->execs) FFGPU_CHECK(hipStreamSynchronize(ex->own_stream));
     return 0;
 }
 
@@ -779,6 +802,41 @@ extern "C" float ffgpu_groupconv_time_dev(const float *d_in, const float *d_filt
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ms * 1000.f / iters;
+}
+
+extern "C" float ffgpu_irb_dev(const float *d_in, const float *d_w1, const float *d_wd, const float *d_w2,
+                               const float *d_res, float *d_out, int batch, int iw, int ih, int ic, int ec, int oc,
+                               int stride, int act1, int actd, int act2, int res_act, int warmup, int iters, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    IrbDesc d{};
+    d.in = d_in; d.out = d_out; d.residual = d_res; d.w1 = d_w1; d.wd = d_wd; d.w2 = d_w2;
+    d.N = batch; d.H = ih; d.W = iw; d.OH = (ih + 2 - 3) / stride + 1; d.OW = (iw + 2 - 3) / stride + 1;
+    d.ic = ic; d.ec = ec; d.oc = oc; d.stride = stride;
+    d.act1 = act1; d.actd = actd; d.act2 = act2; d.res_act = res_act;
+    if (!d_in || !d_out || !d_w1 || !d_wd || !d_w2 || !ffgpu_irb_supported(d)) { ffgpu_set_error("irb_dev: unsupported block shape"); return -1.f; }
+    float *pk = nullptr;
+    if (hipMalloc(&pk, ffgpu_irb_pack_floats(d) * sizeof(float)) != hipSuccess) { ffgpu_set_error("irb_dev: hipMalloc failed"); return -1.f; }
+    d.pk = pk;
+    float us = 0.f;
+    int rc = ffgpu_irb_pack(d, pk, s);
+    if (!rc && iters <= 0) rc = ffgpu_launch_irb(d, s);
+    if (!rc && iters > 0) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int i = 0; i < warmup && !rc; i++) rc = ffgpu_launch_irb(d, s);
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters && !rc; i++) rc = ffgpu_launch_irb(d, s);
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        us = ms * 1000.f / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(pk);
+    return rc ? -1.f : us;
 }
 
 // -------------------------------------------------------------------------- conv.h drop-in (host pointers)

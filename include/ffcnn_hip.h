@@ -144,6 +144,15 @@ float ffgpu_groupconv_time_dev(const float *d_in, const float *d_filt, float *d_
                                int fs, int fn, int ow, int oh, int oc, int act,
                                int flags, int variant, int warmup, int iters, void *stream);
 
+/* Fused block: 1x1 expand -> depthwise 3x3 (stride 1|2, pad 1) -> 1x1 project [+ residual], i.e.
+ * three consecutive groupconv calls of the reference plus the shortcut that follows them
+ * (ffcnn.c:418-423) in one kernel; the expanded tensors never leave the CU.  CNHW device
+ * tensors; d_w1/d_wd/d_w2 are the three layers' filter rows (conv.h layout); d_res may be NULL.
+ * iters > 0: returns mean microseconds per launch (HIP events on `stream`) instead of 0. */
+float ffgpu_irb_dev(const float *d_in, const float *d_w1, const float *d_wd, const float *d_w2,
+                    const float *d_res, float *d_out, int batch, int iw, int ih, int ic, int ec, int oc,
+                    int stride, int act1, int actd, int act2, int res_act, int warmup, int iters, void *stream);
+
 /* ---- diagnostics -------------------------------------------------------- */
 /* HBM stream calibration on this GPU: mean microseconds per pass over `bytes`
  * (16-byte lanes, grid-stride, `blocks` workgroups of 256).  mode 0: copy,

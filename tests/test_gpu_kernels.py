@@ -132,3 +132,34 @@ def test_full_size_properties(env):
     for (r, c) in ((100, 255), (200, 256)):
         patch = y3[:, r - 1:r + 2, c - 1:c + 2]
         assert torch.allclose(patch, torch.flip(taps, dims=(1, 2)), atol=1e-6), (r, c)
+
+
+IRB_SHAPES = [  # (ic, ec, oc, stride, N, H, W, residual)
+    (8, 32, 8, 1, 2, 80, 80, True), (4, 24, 8, 2, 2, 160, 160, False), (8, 48, 16, 1, 3, 40, 40, False),
+    (16, 96, 16, 1, 2, 40, 40, True), (16, 96, 24, 2, 2, 40, 40, False), (24, 136, 24, 1, 3, 20, 20, True),
+    (24, 136, 48, 2, 2, 20, 20, False), (48, 224, 48, 1, 3, 10, 10, True), (8, 8, 4, 1, 1, 32, 48, False),
+    (4, 8, 4, 1, 2, 16, 16, True), (12, 40, 20, 1, 1, 12, 20, True), (6, 30, 10, 2, 2, 16, 12, False),
+]
+
+
+@pytest.mark.parametrize("shape", IRB_SHAPES)
+def test_irb_fused_block(env, shape):
+    """fused expand->dw3x3->project(+shortcut) == three generic groupconv launches + add on the same tensors"""
+    capi, torch = env
+    ic, ec, oc, stride, N, H, W, use_res = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f1, fd, f2 = make_filter(rng, ec, ic), make_filter(rng, ec, 9), make_filter(rng, oc, ec)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = rng.uniform(-1, 1, (oc * N, OH, OW)).astype(np.float32)
+    e1 = run_dev(capi, torch, x, f1, N, W, H, ic, 1, 0, 1, 1, ec, 2, capi.FFGPU.K_GENERIC)
+    e2 = run_dev(capi, torch, e1, fd, N, W, H, ec, ec, 1, stride, 3, ec, 2, capi.FFGPU.K_GENERIC)
+    ref = run_dev(capi, torch, e2, f2, N, OW, OH, ec, 1, 0, 1, 1, oc, 0, capi.FFGPU.K_GENERIC)
+    if use_res:
+        ref = ref + res
+    t = [torch.from_numpy(a).cuda() for a in (x, f1, fd, f2, res)]
+    out = torch.full((oc * N, OH, OW), float("nan"), device="cuda")
+    capi.irb_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr() if use_res else None,
+                 out.data_ptr(), N, W, H, ic, ec, oc, stride)
+    torch.cuda.synchronize()
+    check(out.cpu().numpy(), ref, "irb %s" % (shape,))
