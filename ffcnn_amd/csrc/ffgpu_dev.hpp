@@ -23,6 +23,7 @@ struct ConvDesc {
     const float *filt;     // fn rows of K4+4 floats (conv.h layout)
     float       *out;
     const float *residual; // optional: out = act2(conv_act(...) + residual), same layout as out (fused shortcut)
+    const float *wpack;    // optional: plan-time LDS image of the weights (ffgpu_pw_pack), pointwise layers only
     int   N;
     int   iw, ih, ic;
     int   ow, oh, oc;
@@ -47,6 +48,9 @@ bool   ffgpu_irb_supported(const IrbDesc &d);
 size_t ffgpu_irb_pack_floats(const IrbDesc &d);
 int    ffgpu_irb_pack(const IrbDesc &d, float *pk, hipStream_t s);
 int    ffgpu_launch_irb(const IrbDesc &d, hipStream_t s);
+
+size_t ffgpu_pw_pack_floats(const ConvDesc &d);
+int    ffgpu_pw_pack(const ConvDesc &d, float *pk, hipStream_t s);
 
 // kernels.hip
 int         ffgpu_launch_conv(const ConvDesc &d, int variant, hipStream_t s);

@@ -380,11 +380,17 @@ static int plan(ffgpu_exec *ex)
     }
     {   // constants of the fused blocks, packed once into their LDS image
         size_t tot = 0;
-        for (Step &st : S) if (st.kind == S_IRB) tot += ffgpu_irb_pack_floats(st.irb);
+        for (Step &st : S) {
+            if (st.kind == S_IRB) tot += ffgpu_irb_pack_floats(st.irb);
+            if (st.kind == S_CONV && !st.in_is_input) tot += ffgpu_pw_pack_floats(st.conv);
+        }
         if (tot) {
             if (hipMalloc(&ex->d_pack, tot * sizeof(float)) != hipSuccess) { ffgpu_set_error("hipMalloc(pack) failed"); return -1; }
             size_t off = 0;
-            for (Step &st : S) if (st.kind == S_IRB) { st.irb.pk = ex->d_pack + off; off += ffgpu_irb_pack_floats(st.irb); }
+            for (Step &st : S) {
+                if (st.kind == S_IRB) { st.irb.pk = ex->d_pack + off; off += ffgpu_irb_pack_floats(st.irb); }
+                if (st.kind == S_CONV && !st.in_is_input && ffgpu_pw_pack_floats(st.conv)) { st.conv.wpack = ex->d_pack + off; off += ffgpu_pw_pack_floats(st.conv); }
+            }
         }
     }
     if (bad_chain) { ffgpu_set_error("a layer consumes the (non-existent) output of a yolo head"); return -1; }
@@ -396,8 +402,10 @@ static int plan(ffgpu_exec *ex)
 
 static int repack(ffgpu_exec *ex, hipStream_t s)
 {
-    for (const Step &st : ex->steps)
+    for (const Step &st : ex->steps) {
         if (st.kind == S_IRB && ffgpu_irb_pack(st.irb, const_cast<float *>(st.irb.pk), s)) return -1;
+        if (st.kind == S_CONV && st.conv.wpack && ffgpu_pw_pack(st.conv, const_cast<float *>(st.conv.wpack), s)) return -1;
+    }
     return 0;
 }
 

@@ -170,6 +170,9 @@ __global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *
     const long cs = (long)N * cells;                                  // CNHW channel stride
     const float *p = hd.in + (long)k * (5 + hd.classes) * cs + (long)n * cells + cell;
     const float bs = p[4 * cs];
+    // conf = 1 / (1 + e^-bs (1 + e^-cs)) <= 1 / (1 + e^-bs): cells whose objectness alone cannot reach the
+    // threshold (almost all of them) skip the 80-class scan.  0.1 % slack keeps the shortcut rounding-proof.
+    if (1.0f / (1.0f + __expf(-bs)) < hd.thresh * 0.999f) return;
     float cs_best = p[5 * cs];
     int best = 0;
     for (int l = 1; l < hd.classes; l++) {

@@ -94,6 +94,38 @@ def test_pw_mfma(env, orc, shape):
             check(got.reshape(oc, N, H, W)[:, n], o, "pw_mfma %s frame %d vs oracle" % (shape, n))
 
 
+DWL_SHAPES = [  # (C, N, H, W, fs, stride, act, compat)
+    (24, 2, 160, 160, 3, 2, 2, 0), (32, 1, 80, 80, 3, 2, 2, 0), (136, 2, 20, 20, 3, 1, 2, 0), (224, 3, 10, 10, 3, 1, 2, 0),
+    (96, 2, 10, 10, 5, 1, 2, 0), (96, 2, 10, 10, 5, 1, 2, 1), (120, 1, 20, 20, 5, 1, 2, 0), (120, 2, 20, 20, 5, 1, 2, 1),
+    (5, 3, 7, 9, 3, 1, 0, 0), (4, 1, 7, 7, 3, 2, 1, 0), (3, 2, 6, 8, 5, 1, 2, 0), (2, 1, 33, 45, 5, 2, 2, 0), (3, 1, 1, 1, 3, 1, 2, 0),
+]
+
+
+@pytest.mark.parametrize("shape", DWL_SHAPES)
+def test_dw_lds(env, orc, shape):
+    capi, torch = env
+    C, N, H, W, fs, stride, act, compat = shape
+    pad = fs // 2
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (C * N, H, W)).astype(np.float32)
+    f = make_filter(rng, C, fs * fs)
+    flags = capi.FFGPU.COMPAT_V6 if compat else 0
+    assert capi.kernel_name(N, W, H, C, C, pad, stride, fs, C, capi.FFGPU.K_DW_LDS) == "dw_lds"
+    OH, OW = (H + 2 * pad - fs) // stride + 1, (W + 2 * pad - fs) // stride + 1
+    dx, df = torch.from_numpy(x).cuda(), torch.from_numpy(f).cuda()
+    outs = []
+    for variant in (capi.FFGPU.K_DW_LDS, capi.FFGPU.K_GENERIC):
+        dy = torch.full((C * N, OH, OW), float("nan"), device="cuda")
+        capi.groupconv_dev(dx.data_ptr(), df.data_ptr(), dy.data_ptr(), N, W, H, C, C, pad, stride, fs, C, act, flags, variant, None)
+        torch.cuda.synchronize()
+        outs.append(dy.cpu().numpy())
+    check(outs[0], outs[1], "dw_lds %s vs generic" % (shape,))
+    xf = x.reshape(C, N, H, W)
+    for n in range(N):
+        o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, C, pad, stride, fs, act, compat)
+        check(outs[0].reshape(C, N, OH, OW)[:, n], o, "dw_lds %s frame %d vs oracle" % (shape, n))
+
+
 def test_unsupported_variant_fails_loudly(env):
     capi, torch = env
     x = torch.zeros((4, 7, 7), device="cuda")          # W % 4 != 0: the stream kernel must refuse
