@@ -155,9 +155,12 @@ def kernel_roofline(torch, capi, stream):
     filt[:, 13] = torch.rand((Cc,), device="cuda", generator=g) * 0.2 - 0.1
     torch.cuda.synchronize()
     us = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, Cc, Cc, 1, 1, 3, Cc, act=2,
-                                 warmup=5, iters=30, stream=stream.cuda_stream)
+                                 warmup=10, iters=50, stream=stream.cuda_stream)
     alg_bytes = 2 * N * Cc * H * W * 4
     name = capi.kernel_name(N, W, H, Cc, Cc, 1, 1, 3, Cc)
+    # context: what a bare 16-byte copy / read of the same bytes reaches on THIS GPU (ffgpu_membench)
+    copy_us = min(capi.lib().ffgpu_membench(y.data_ptr(), x.data_ptr(), alg_bytes // 2, 0, b, 10, stream.cuda_stream) for b in (1024, 2048))
+    read_us = capi.lib().ffgpu_membench(y.data_ptr(), x.data_ptr(), alg_bytes // 2, 2, 2048, 10, stream.cuda_stream)
     gbs = alg_bytes / (us * 1e-6) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "dw3x3_traffic.json")     # per-launch HBM bytes from the PMC passes
@@ -169,7 +172,8 @@ def kernel_roofline(torch, capi, stream):
     del x, y
     return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "us_per_launch": round(us, 2),
-            "algorithmic_bytes": alg_bytes, "workload": "dw3x3 s1 p1 320x320x64 batch 64 fp32 (BASELINE config[1])"}
+            "algorithmic_bytes": alg_bytes, "workload": "dw3x3 s1 p1 320x320x64 batch 64 fp32 (BASELINE config[1])",
+            "same_box_copy_GBs": round(alg_bytes / copy_us / 1e3, 1), "same_box_read_GBs": round(alg_bytes / 2 / read_us / 1e3, 1)}
 
 
 def pw_roofline(torch, capi, stream):
@@ -205,6 +209,7 @@ def main():
     import torch
     import torch.distributed as dist
     from ffcnn_amd import capi
+    from ffcnn_amd import dist as ffdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -221,16 +226,21 @@ def main():
 
     B = FRAMES_PER_GPU
     stream = torch.cuda.Stream()
+    roof = roof_pw = None
+    if world == 1 and not args.no_kernel_roofline:      # single-kernel rooflines first, on a fresh allocator
+        roof = kernel_roofline(torch, capi, stream)
+        roof_pw = pw_roofline(torch, capi, stream)
+        torch.cuda.empty_cache()
     net = capi.Net()
     # weights: rank 0's folded filter rows -> every GPU over RCCL (one-off, outside the timed region)
     wptr, wbytes = net.weights_dev()
     if world > 1:
         wt = dev_tensor(torch, wptr, wbytes, "<f4")
         if rank != 0:
-            wt.zero_()
-        dist.broadcast(wt, src=0)
+            wt.zero_()                       # prove the weights really arrive over RCCL
+        ffdist.broadcast_weights(dist, wt, src=0)
         torch.cuda.synchronize()
-        net.weights_commit()
+        net.weights_commit()                 # refresh the packed LDS images derived from the filter rows
     ex = net.executor(B)
 
     # synthetic frames (seeded per rank); frame 0 of rank 0 is the letterboxed test.bmp so boxes can be checked
@@ -257,7 +267,7 @@ def main():
     def step():
         ex.forward_dev(x.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.gather(dets, gathered, dst=0)
+            ffdist.gather_records(dist, dets, dst=0, out=gathered)
             if rank == 0:
                 for r in range(world):
                     host[r].copy_(gathered[r], non_blocking=True)
@@ -305,9 +315,9 @@ def main():
                        "weights": "data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL, untimed)",
                        "boxes_match_reference_golden_frame0": ok},
         }
-        if world == 1 and not args.no_kernel_roofline:
-            out["roofline"] = kernel_roofline(torch, capi, stream)
-            out["roofline_pw"] = pw_roofline(torch, capi, stream)
+        if roof is not None:
+            out["roofline"] = roof
+            out["roofline_pw"] = roof_pw
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_vs_cpu_1thread"] = round(fps / out["cpu_baseline"]["value"], 1) if out["cpu_baseline"]["value"] else None

@@ -1,0 +1,87 @@
+"""The N > 1 path on CPU: world_size 2, gloo.  Exercises exactly what bench.py does between the
+kernels -- contiguous frame shards, one broadcast of the filter rows, a gather of fixed-size
+detection records to rank 0, merged back into global frame order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ffcnn_amd import dist as ffdist
+from ffcnn_amd.capi import DETS_DTYPE, FFGPU
+
+
+def test_shard_range_covers_batch():
+    for total in (1, 7, 64, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [ffdist.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert ffdist.shard_range(256, 3, 8) == (96, 128)       # BASELINE config[4]: 32 contiguous frames per GPU
+
+
+def fake_records(lo, hi):
+    """deterministic per-frame records: frame g has (g % 5) boxes whose fields encode g"""
+    rec = np.zeros(hi - lo, DETS_DTYPE)
+    for i, g in enumerate(range(lo, hi)):
+        k = g % 5
+        rec[i]["count"] = k
+        rec[i]["ncand"] = 2 * k
+        for b in range(k):
+            rec[i]["box"][b] = (g % 80, 0.5 + 0.01 * b, g, g + 1, g + 2 + b, g + 3)
+    return rec
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # 1. weights: rank 0 holds them, everybody else zeros -> broadcast
+        w = torch.arange(356576, dtype=torch.float32) if rank == 0 else torch.zeros(356576)
+        ffdist.broadcast_weights(dist, w)
+        ok_w = bool(torch.equal(w, torch.arange(356576, dtype=torch.float32)))
+        # 2. shard + per-rank "forward" (fabricated records) + gather to rank 0, three steps
+        lo, hi = ffdist.shard_range(total, rank, world)
+        per = -(-total // world)
+        local = np.zeros(per, DETS_DTYPE)
+        local[: hi - lo] = fake_records(lo, hi)
+        t = torch.from_numpy(local.view(np.uint8).copy())
+        out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+        merged = None
+        for _ in range(3):
+            got = ffdist.gather_records(dist, t, dst=0, out=out)
+            if rank == 0:
+                sizes = [ffdist.shard_range(total, r, world) for r in range(world)]
+                merged = ffdist.merge_records([g.numpy() for g in got], [b - a for a, b in sizes], DETS_DTYPE)
+        dist.barrier()
+        if rank == 0:
+            want = fake_records(0, total)
+            q.put((ok_w, bool(np.array_equal(merged, want)), len(merged)))
+        else:
+            q.put((ok_w, True, 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [8, 7])
+def test_two_rank_broadcast_and_gather(total):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[0] and r[1] for r in res), res
+    assert sorted(r[2] for r in res) == [0, total]
+    assert DETS_DTYPE.itemsize == 16 + 24 * FFGPU.MAX_DET

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Per-launch HBM bytes of dw3_stream from the FETCH_SIZE / WRITE_SIZE passes, corrected as the guide
+prescribes: counters are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests as 64 B for wide coalesced
+reads (x2); both are CALIBRATED on a bare 16-byte copy of a known byte count captured in the same pass
+(k_membench<0>: exactly `nbytes` read and `nbytes` written per launch)."""
+import json, sqlite3, sys
+
+NBYTES = 64 * 64 * 320 * 320 * 4
+
+
+def per_kernel(dbpath, counter):
+    db = sqlite3.connect(dbpath)
+    rows = db.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
+    return {k.split("(")[0]: (v, n) for k, v, n in rows}
+
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+
+
+def pick(d, key):
+    for k, v in d.items():
+        if key in k:
+            return v[0]
+    raise SystemExit("kernel %s not in profile: %s" % (key, list(d)))
+
+
+cal_r = pick(fetch, "k_membench") * 1024.0      # raw bytes the counter reports for NBYTES really read
+cal_w = pick(write, "k_membench") * 1024.0
+dw_r_raw = pick(fetch, "k_dw3_stream") * 1024.0
+dw_w_raw = pick(write, "k_dw3_stream") * 1024.0
+fr, fw = NBYTES / cal_r, NBYTES / cal_w           # calibration factors (guide: expect ~2.0 for reads)
+res = {
+    "kernel": "k_dw3_stream<2,4,false>", "workload": "dw3x3 s1 p1 320x320x64 batch 64 fp32",
+    "algorithmic_bytes_per_launch": 2 * NBYTES,
+    "raw_FETCH_SIZE_bytes": dw_r_raw, "raw_WRITE_SIZE_bytes": dw_w_raw,
+    "calibration": {"copy_bytes_each_way": NBYTES, "raw_FETCH_copy": cal_r, "raw_WRITE_copy": cal_w,
+                    "read_factor": round(fr, 4), "write_factor": round(fw, 4)},
+    "hbm_read_bytes_per_launch": round(dw_r_raw * fr), "hbm_write_bytes_per_launch": round(dw_w_raw * fw),
+}
+res["hbm_bytes_per_launch"] = res["hbm_read_bytes_per_launch"] + res["hbm_write_bytes_per_launch"]
+res["traffic_over_algorithmic"] = round(res["hbm_bytes_per_launch"] / (2.0 * NBYTES), 4)
+print(json.dumps(res, indent=1))
+json.dump(res, open("gpurun_out/dw3x3_traffic.json", "w"), indent=1)
