@@ -240,3 +240,21 @@ def test_missing_weights_and_bad_cfg(F):
         assert not n.weights_host().any()
         n.forward()
         assert n.n.bbox_num == 0
+
+
+def test_reference_main_on_hip_groupconv():
+    """Level-1 drop-in: the reference's unmodified main/ffcnn.c (oracle/_ref/ffcnn_ref_dropin, built from
+    /root/reference by oracle/Makefile) with ONLY groupconv taken from libffcnn_hip.so prints the CLI's boxes."""
+    import re
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "ffcnn_ref_dropin")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ffcnn_ref_dropin not built (needs /root/reference at build time)")
+    data = os.path.join(ROOT, "data")
+    out = subprocess.run([exe, "2", os.path.join(data, "test.bmp"), os.path.join(data, "yolo-fastest-1.1.cfg"),
+                          os.path.join(data, "yolo-fastest-1.1.weights")], capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert out.returncode == 0, out.stderr[-500:]
+    boxes = re.findall(r"score: ([0-9.]+), category:\s*(\d+), rect: \(\s*(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\)", out.stdout)
+    got = [(int(c), int(a), int(b), int(cc), int(d)) for _, c, a, b, cc, d in boxes]
+    assert got == [(0, 188, 96, 273, 365), (18, 397, 125, 601, 345), (16, 68, 264, 201, 350)], out.stdout[-800:]
