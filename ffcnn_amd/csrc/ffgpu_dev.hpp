@@ -45,6 +45,7 @@ struct IrbDesc {
     const float *pk;          // packed constants (ffgpu_irb_pack_floats floats, filled by ffgpu_irb_pack)
 };
 bool   ffgpu_irb_supported(const IrbDesc &d);
+bool   ffgpu_irb_is_thin(const IrbDesc &d);      // 8 expanded channels: streaming VALU kernel instead of the MFMA/LDS one
 size_t ffgpu_irb_pack_floats(const IrbDesc &d);
 int    ffgpu_irb_pack(const IrbDesc &d, float *pk, hipStream_t s);
 int    ffgpu_launch_irb(const IrbDesc &d, hipStream_t s);

@@ -189,7 +189,7 @@ static int plan(ffgpu_exec *ex)
             d.act1 = a.activation; d.actd = b.activation; d.act2 = c.activation;
             d.res_act = fused_into[p0 + 2] >= 0 ? ll[fused_into[p0 + 2]].activation : 0;
             static const int min_ec = getenv("FFGPU_IRB_MIN_EC") ? atoi(getenv("FFGPU_IRB_MIN_EC")) : 24;
-            if (d.ec < min_ec || !ffgpu_irb_supported(d)) continue;   // thin blocks: three streaming kernels are faster (profiles/)
+            if ((d.ec < min_ec && !ffgpu_irb_is_thin(d)) || !ffgpu_irb_supported(d)) continue;   // thin blocks take the streaming fused kernel
             irb_tail[p0 + 2] = p0;
             canon[p0] = canon[p0 + 1] = -3;
             p0 += 2;
