@@ -799,6 +799,12 @@ extern "C" float ffgpu_groupconv_time_dev(const float *d_in, const float *d_filt
     hipStream_t s = (hipStream_t)stream;
     ConvDesc d;
     fill_desc(d, d_in, d_filt, d_out, batch, iw, ih, ic, groups, pad, stride, fs, ow, oh, oc, act, flags);
+    // like the executor, hand pointwise kernels their plan-time weight image (packed once, outside the timed loop)
+    float *pk = nullptr;
+    if (variant == FFGPU_K_AUTO && ffgpu_pw_pack_floats(d) > 0) {
+        if (hipMalloc(&pk, ffgpu_pw_pack_floats(d) * sizeof(float)) != hipSuccess || ffgpu_pw_pack(d, pk, s)) { ffgpu_set_error("pack failed"); return -1.f; }
+        d.wpack = pk;
+    }
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { ffgpu_set_error("hipEventCreate failed"); return -1.f; }
     for (int i = 0; i < warmup; i++) if (ffgpu_launch_conv(d, variant, s)) return -1.f;

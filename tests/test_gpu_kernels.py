@@ -126,6 +126,23 @@ def test_dw_lds(env, orc, shape):
         check(outs[0].reshape(C, N, OH, OW)[:, n], o, "dw_lds %s frame %d vs oracle" % (shape, n))
 
 
+@pytest.mark.parametrize("shape", [(256, 512, 2, 20, 20, 2), (128, 255, 1, 20, 20, 0), (64, 130, 3, 10, 10, 2), (100, 200, 1, 12, 12, 1)])
+def test_pw_gemm(env, orc, shape):
+    capi, torch = env
+    ic, oc, N, H, W, act = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f = make_filter(rng, oc, ic)
+    assert capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc, capi.FFGPU.K_PW_GEMM) == "pw_gemm"
+    got = run_dev(capi, torch, x, f, N, W, H, ic, 1, 0, 1, 1, oc, act, capi.FFGPU.K_PW_GEMM)
+    ref = run_dev(capi, torch, x, f, N, W, H, ic, 1, 0, 1, 1, oc, act, capi.FFGPU.K_GENERIC)
+    check(got, ref, "pw_gemm %s vs generic" % (shape,))
+    if ic * oc * N * H * W <= 4e7:
+        xf = x.reshape(ic, N, H, W)
+        o = orc.groupconv(np.ascontiguousarray(xf[:, 0]), f, 1, 0, 1, 1, act)
+        check(got.reshape(oc, N, H, W)[:, 0], o, "pw_gemm %s frame 0 vs oracle" % (shape,))
+
+
 def test_unsupported_variant_fails_loudly(env):
     capi, torch = env
     x = torch.zeros((4, 7, 7), device="cuda")          # W % 4 != 0: the stream kernel must refuse
