@@ -204,6 +204,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="one executor, gather on the compute stream")
     args = ap.parse_args()
 
     import torch
@@ -235,13 +236,16 @@ def main():
     # weights: rank 0's folded filter rows -> every GPU over RCCL (one-off, outside the timed region)
     wptr, wbytes = net.weights_dev()
     if world > 1:
-        wt = dev_tensor(torch, wptr, wbytes, "<f4")
-        if rank != 0:
-            wt.zero_()                       # prove the weights really arrive over RCCL
-        ffdist.broadcast_weights(dist, wt, src=0)
+        wt = dev_tensor(torch, wptr, wbytes, "<f4")             # view of the library's device buffer
+        wtmp = wt.clone() if rank == 0 else torch.zeros_like(wt)    # non-zero ranks start from zeros: the
+        ffdist.broadcast_weights(dist, wtmp, src=0)                 # weights really arrive over RCCL
+        wt.copy_(wtmp)
         torch.cuda.synchronize()
         net.weights_commit()                 # refresh the packed LDS images derived from the filter rows
-    ex = net.executor(B)
+    # two executors used alternately: while step i's records are gathered / copied to the host on a side stream,
+    # step i+1 already runs on the compute stream (the gather is latency-bound)
+    exs = [net.executor(B), net.executor(B)] if not args.no_overlap else [net.executor(B)]
+    ex = exs[0]
 
     # synthetic frames (seeded per rank); frame 0 of rank 0 is the letterboxed test.bmp so boxes can be checked
     g = torch.Generator(device="cuda").manual_seed(1236 + rank)
@@ -257,22 +261,38 @@ def main():
             check = json.load(open(os.path.join(ROOT, "tests", "golden", "boxes.json")))["net_320x320_v0"]["boxes"]
         except Exception as e:
             print("bench: golden check unavailable: %r" % (e,), file=sys.stderr)
-    ex.set_scale(640, 320)      # every frame is treated as a 640-wide source letterboxed to 320 (test.bmp's ratio)
+    for e in exs:
+        e.set_scale(640, 320)   # every frame is treated as a 640-wide source letterboxed to 320 (test.bmp's ratio)
 
-    dptr, dbytes = ex.dets_dev()
-    dets = dev_tensor(torch, dptr, dbytes)                      # this rank's records (uint8 view)
-    gathered = [torch.empty_like(dets) for _ in range(world)] if (world > 1 and rank == 0) else None
-    host = torch.empty((world, dbytes), dtype=torch.uint8).pin_memory() if rank == 0 else None
+    nex = len(exs)
+    dets = []
+    for e in exs:
+        dptr, dbytes = e.dets_dev()
+        dets.append(dev_tensor(torch, dptr, dbytes))            # this rank's records (uint8 view of the library's buffer)
+    send = [torch.empty_like(d) for d in dets] if world > 1 else None
+    big = torch.empty((world, dbytes), dtype=torch.uint8, device="cuda") if (world > 1 and rank == 0) else None
+    glist = list(big.unbind(0)) if big is not None else None
+    host = [torch.empty((world, dbytes), dtype=torch.uint8).pin_memory() for _ in range(nex)] if rank == 0 else None
+    comm = torch.cuda.Stream() if nex > 1 else stream
+    ev_fwd = [torch.cuda.Event() for _ in range(nex)]
+    ev_comm = [torch.cuda.Event() for _ in range(nex)]
 
-    def step():
-        ex.forward_dev(x.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            ffdist.gather_records(dist, dets, dst=0, out=gathered)
-            if rank == 0:
-                for r in range(world):
-                    host[r].copy_(gathered[r], non_blocking=True)
-        else:
-            host[0].copy_(dets, non_blocking=True)
+    def step(i):
+        k = i % nex
+        with torch.cuda.stream(stream):
+            stream.wait_event(ev_comm[k])                       # this executor's previous records have been shipped
+            exs[k].forward_dev(x.data_ptr(), stream.cuda_stream)
+            ev_fwd[k].record(stream)
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev_fwd[k])
+            if world > 1:
+                send[k].copy_(dets[k])                          # torch-owned staging tensor for the collective
+                ffdist.gather_records(dist, send[k], dst=0, out=glist)
+                if rank == 0:
+                    host[k].copy_(big, non_blocking=True)       # one D2H copy for the whole job's records
+            else:
+                host[k][0].copy_(dets[k], non_blocking=True)
+            ev_comm[k].record(comm)
 
     def fence():
         torch.cuda.synchronize()
@@ -280,15 +300,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dt = time.perf_counter() - t0
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    last = (args.warmup + args.steps - 1) % nex
     tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -299,7 +319,7 @@ def main():
         fps = B * world * args.steps / dt
         ok = None
         if check is not None:
-            rec = np.frombuffer(host[0].numpy().tobytes(), capi.DETS_DTYPE, B)
+            rec = np.frombuffer(host[last][0].numpy().tobytes(), capi.DETS_DTYPE, B)
             got = rec[0]["box"][: rec[0]["count"]]
             ok = bool(len(got) == len(check) and all(
                 int(a["type"]) == int(b["type"]) and abs(float(a["score"]) - float(b["score"])) < 1e-4 and
@@ -312,6 +332,7 @@ def main():
             "config": {"workload": "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[3]/[4])",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "launches_per_step": ex.kernel_count, "arena_MB": round(ex.arena_bytes / 2**20, 1),
+                       "executors": nex, "gather": "overlapped with the next step on a side stream" if nex > 1 else "in line",
                        "weights": "data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL, untimed)",
                        "boxes_match_reference_golden_frame0": ok},
         }
@@ -322,7 +343,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
             out["gpu_vs_cpu_1thread"] = round(fps / out["cpu_baseline"]["value"], 1) if out["cpu_baseline"]["value"] else None
         print(json.dumps(out))
-    ex.close()
+    for e in exs:
+        e.close()
     net.close()
     if world > 1:
         dist.destroy_process_group()
