@@ -258,3 +258,58 @@ def test_reference_main_on_hip_groupconv():
     boxes = re.findall(r"score: ([0-9.]+), category:\s*(\d+), rect: \(\s*(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\)", out.stdout)
     got = [(int(c), int(a), int(b), int(cc), int(d)) for _, c, a, b, cc, d in boxes]
     assert got == [(0, 188, 96, 273, 365), (18, 397, 125, 601, 345), (16, 68, 264, 201, 350)], out.stdout[-800:]
+
+
+def _write_random_weights(path, orc_net, seed):
+    """darknet .weights for an arbitrary cfg: 20-byte header, then per conv layer biases | [scales, means, vars] | taps"""
+    rng = np.random.default_rng(seed)
+    with open(path, "wb") as fp:
+        fp.write(np.array([0, 2, 5], "<i4").tobytes() + np.array([0], "<u8").tobytes())
+        for i in range(orc_net.nlayers):
+            L = orc_net.layer(i)
+            if L.kind != 0:
+                continue
+            K = L.fs * L.fs * (L.ic // L.groups)
+            fp.write(rng.uniform(-0.2, 0.2, L.fn).astype("<f4").tobytes())
+            if L.batchnorm:
+                fp.write(rng.uniform(0.5, 1.5, L.fn).astype("<f4").tobytes())
+                fp.write(rng.uniform(-0.3, 0.3, L.fn).astype("<f4").tobytes())
+                fp.write(rng.uniform(0.2, 1.0, L.fn).astype("<f4").tobytes())
+            fp.write((rng.uniform(-1, 1, L.fn * K) * (1.6 / np.sqrt(K))).astype("<f4").tobytes())
+
+
+@pytest.mark.parametrize("flags", [1, 0])      # 1: KEEP_ALL | NO_FUSE with per-layer checks, 0: default fused graph executor
+def test_other_cfg_generic_path(F, orc, tmp_path, flags):
+    """a cfg that is NOT yolo-fastest (tests/data/mini.cfg: grouped 3x3, dense 5x5 s2, unpadded 3x3, avgpool, relu,
+    shortcut with leaky, multi-source route, upsample, two heads with 2 classes): every layer and the boxes against
+    the oracle -- the generic kernels and the planner on a graph they were not tuned for."""
+    from conftest import ROOT
+    cfg = os.path.join(ROOT, "tests", "data", "mini.cfg")
+    o = orc.Oracle(cfg=cfg, weights=None)
+    wpath = str(tmp_path / "mini.weights")
+    _write_random_weights(wpath, o, 42)
+    o.close()
+    o = orc.Oracle(cfg=cfg, weights=wpath)
+    rng = np.random.default_rng(5)
+    frames = rng.uniform(0, 1, (3, 3, 48, 64)).astype(np.float32)
+    keep = F.FFGPU.KEEP_ALL | F.FFGPU.NO_FUSE if flags else 0
+    with F.Net(cfg, wpath) as n:
+        assert n.layer_num == o.nlayers == 18
+        assert np.array_equal(n.weights_host(), o.weights())
+        with n.executor(3, keep) as ex:
+            ex.set_scale(3, 2)
+            ex.forward_host(frames)
+            dets = ex.read_dets()
+            for f in range(3):
+                o.input[...] = frames[f]
+                o.n.s1, o.n.s2 = 3, 2
+                o.forward(0)
+                if keep:
+                    for i in range(o.nlayers):
+                        ref = o.layer_out(i)
+                        if ref is None or n.layer(i).type == 4:
+                            continue
+                        close(ex.read_layer(i, f), ref, "mini frame %d layer %d" % (f, i))
+                assert dets[f]["ncand"] == len(o.candidates)
+                boxes_match(ex.boxes(f, dets), o.boxes, "mini boxes frame %d" % f)
+    o.close()
