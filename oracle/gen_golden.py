@@ -16,6 +16,8 @@ Fixtures are data (inputs + the reference's outputs); no reference source text.
                         its specialised path is defined)
   net_dump.txt          the reference's layer table
   input_320.npz         net_input result checksum + samples
+  cli.json              the reference CLI (oracle/_ref/ffcnn_ref_cli_v6 = build.sh's default link) on
+                        data/test.bmp: printed detection lines and the sha256 of the out.bmp it writes
 """
 import json
 import os
@@ -81,6 +83,21 @@ def make_case(rng, ic, ih, iw, groups, fs, fn):
     return x, f
 
 
+def cli_golden():
+    import hashlib
+    import tempfile
+    exe = os.path.join(HERE, "_ref", "ffcnn_ref_cli_v6")
+    with tempfile.TemporaryDirectory() as d:
+        out = subprocess.run([exe, "1", orc.BMP, orc.CFG, orc.WEIGHTS], capture_output=True, text=True, check=True, cwd=d).stdout
+        sha = hashlib.sha256(open(os.path.join(d, "out.bmp"), "rb").read()).hexdigest()
+    lines = out.splitlines()
+    res = dict(detections=[l for l in lines if l.startswith("score:")], out_bmp_sha256=sha,
+               head=[l.split(":")[0].strip() for l in lines[:3]],
+               layer_table=[l for l in lines if l[:3].strip().isdigit() or l.startswith("layer")])
+    json.dump(res, open(os.path.join(GOLD, "cli.json"), "w"), indent=1)
+    return res
+
+
 def main():
     orc.build()
     os.makedirs(GOLD, exist_ok=True)
@@ -142,6 +159,7 @@ def main():
             "r = orc.Ref('v0'); r.L.net_dump(r.p); import ctypes; ctypes.CDLL(None).fflush(None)") % ROOT
     txt = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout
     open(os.path.join(GOLD, "net_dump.txt"), "w").write(txt)
+    cli_golden()
     print("golden written to", GOLD)
     for fn_ in sorted(os.listdir(GOLD)):
         print("  %-24s %8d B" % (fn_, os.path.getsize(os.path.join(GOLD, fn_))))

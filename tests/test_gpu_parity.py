@@ -313,3 +313,21 @@ def test_other_cfg_generic_path(F, orc, tmp_path, flags):
                 assert dets[f]["ncand"] == len(o.candidates)
                 boxes_match(ex.boxes(f, dets), o.boxes, "mini boxes frame %d" % f)
     o.close()
+
+
+def test_demo_cli_matches_reference_cli(tmp_path):
+    """ffcnn_hip_demo (the C harness on libffcnn_hip.so) against the reference CLI's own output on test.bmp:
+    same layer table, same printed detections, byte-identical out.bmp (green outlines included)."""
+    import hashlib
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "ffcnn_amd", "bin", "ffcnn_hip_demo")
+    gold = json.load(open(os.path.join(GOLD, "cli.json")))
+    data = os.path.join(ROOT, "data")
+    out = subprocess.run([exe, "3", os.path.join(data, "test.bmp"), os.path.join(data, "yolo-fastest-1.1.cfg"),
+                          os.path.join(data, "yolo-fastest-1.1.weights")], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-400:]
+    lines = out.stdout.splitlines()
+    assert [l for l in lines if l.startswith("score:")] == gold["detections"]
+    assert [l for l in lines if l[:3].strip().isdigit() or l.startswith("layer")] == gold["layer_table"]
+    assert hashlib.sha256(open(tmp_path / "out.bmp", "rb").read()).hexdigest() == gold["out_bmp_sha256"]
