@@ -72,6 +72,7 @@ struct Step {
     int      w, h, c, fs, stride, flag;
     YoloHead head;
     IrbDesc  irb;            // S_IRB: fused expand -> depthwise -> project [+ shortcut]
+    int      lane;           // 0: main stream, 1: side stream (a detection head that runs beside the rest of the net)
 };
 
 struct Tensor {
@@ -110,6 +111,9 @@ struct ffgpu_exec {
     ffgpu_frame_dets *d_dets = nullptr;
     int    s1 = 1, s2 = 1;
     hipStream_t own_stream = nullptr, last_stream = nullptr;
+    hipStream_t side_stream = nullptr;              // second graph branch
+    hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
+    int side_lo = -1, side_hi = -1;                 // layers [side_lo, side_hi] form the side branch
     // graph cache: one instantiated graph per (input pointer, s1, s2)
     struct GraphKey { const float *in; int s1, s2; bool operator<(const GraphKey &o) const {
         return in != o.in ? in < o.in : s1 != o.s1 ? s1 < o.s1 : s2 < o.s2; } };
@@ -237,6 +241,43 @@ static int plan(ffgpu_exec *ex)
         const int r = root_of(T, t);
         T[r].first = std::min(T[r].first, T[t].first);
         T[r].last = std::max(T[r].last, T[t].last);
+    }
+
+    // pass 3b: the first detection head runs BESIDE the rest of the net.  In a yolo cfg the layer after a [yolo]
+    // is a [route] back to a tensor produced at layer r: layers r+1 .. yolo only feed that head, everything after the
+    // yolo only depends on layers <= r, so the two chains become parallel branches of the HIP graph (the head's
+    // 10x10 kernels are latency-bound and hide under the other branch).  Their tensors must then not share arena
+    // space: every tensor born after the fork stays live to the end.
+    ex->side_lo = ex->side_hi = -1;
+    // MEASURED (r01): 1.5 % SLOWER than the single chain on a 64-frame batch (the graph's cross-branch dependencies cost
+    // more than the 10x10 kernels' idle time), so it is opt-in: FFGPU_BRANCH=1.
+    const bool branch = getenv("FFGPU_BRANCH") && atoi(getenv("FFGPU_BRANCH"));
+    if (fuse && branch) {
+        for (int y = 0; y + 1 < L; y++) {
+            if (ll[y].type != LAYER_TYPE_YOLO || ll[y + 1].type != LAYER_TYPE_ROUTE || ll[y + 1].depend_num != 1) continue;
+            const int r = ll[y + 1].depend_list[0];
+            bool ok = r >= 0 && r < y;
+            // nothing after the yolo may read a tensor produced inside (r, y]
+            for (int i = y + 1; i < L && ok; i++)
+                for (int k = 0; k < ll[i].depend_num; k++) if (ll[i].depend_list[k] > r && ll[i].depend_list[k] <= y) ok = false;
+            // nothing inside (r, y] may be a fused block straddling the fork (its first layer must be > r)
+            for (int i = r + 1; i <= y && ok; i++) if (irb_tail[i] >= 0 && irb_tail[i] <= r) ok = false;
+            if (fused_into[r] > r) ok = false;       // the fork tensor's producer was absorbed by a later shortcut
+            if (!ok) continue;
+            ex->side_lo = r + 1; ex->side_hi = y;
+            for (int t = 0; t < L; t++) if (T[t].used && T[t].first > r) T[t].last = L + 1;
+            for (int i = r + 1; i <= y; i++) {       // ... and whatever the side branch READS (its kernels may run late)
+                if (ll[i].type != LAYER_TYPE_ROUTE && src_tensor(i - 1) >= 0) T[src_tensor(i - 1)].last = L + 1;
+                for (int k = 0; k < ll[i].depend_num; k++) if (src_tensor(ll[i].depend_list[k]) >= 0) T[src_tensor(ll[i].depend_list[k])].last = L + 1;
+                if (irb_tail[i] >= 0 && src_tensor(irb_tail[i] - 1) >= 0) T[src_tensor(irb_tail[i] - 1)].last = L + 1;
+            }
+            for (int t = 0; t < L; t++) {
+                if (!T[t].used || T[t].parent < 0) continue;
+                const int rt = root_of(T, t);
+                T[rt].last = std::max(T[rt].last, T[t].last);
+            }
+            break;
+        }
     }
 
     // pass 4: first-fit arena allocation of the roots, 256-byte granules
@@ -395,6 +436,7 @@ static int plan(ffgpu_exec *ex)
     }
     if (bad_chain) { ffgpu_set_error("a layer consumes the (non-existent) output of a yolo head"); return -1; }
     { Step nm{}; nm.kind = S_NMS; nm.layer = -1; nm.ltype = LAYER_TYPE_YOLO; S.push_back(nm); }
+    for (Step &st : S) st.lane = (ex->side_lo >= 0 && st.layer >= ex->side_lo && st.layer <= ex->side_hi) ? 1 : 0;
     ex->kernel_count = (int)S.size();
     (void)nheads;
     return 0;
@@ -448,8 +490,28 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
 
 static int issue_all(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
 {
-    for (const Step &st : ex->steps)
+    bool forked = false, joined = true;
+    for (const Step &st : ex->steps) {
+        if (st.lane == 1 && ex->side_stream) {
+            if (!forked) {                                   // fork: the side branch starts where the main one is now
+                FFGPU_CHECK(hipEventRecord(ex->ev_fork, s));
+                FFGPU_CHECK(hipStreamWaitEvent(ex->side_stream, ex->ev_fork, 0));
+                forked = true; joined = false;
+            }
+            if (issue_step(ex, st, d_frames, ex->side_stream) != 0) return -1;
+            continue;
+        }
+        if (st.kind == S_NMS && !joined) {                   // join before the candidates are consumed
+            FFGPU_CHECK(hipEventRecord(ex->ev_join, ex->side_stream));
+            FFGPU_CHECK(hipStreamWaitEvent(s, ex->ev_join, 0));
+            joined = true;
+        }
         if (issue_step(ex, st, d_frames, s) != 0) return -1;
+    }
+    if (!joined) {
+        FFGPU_CHECK(hipEventRecord(ex->ev_join, ex->side_stream));
+        FFGPU_CHECK(hipStreamWaitEvent(s, ex->ev_join, 0));
+    }
     return 0;
 }
 
@@ -508,6 +570,9 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
     ex->net = net; ex->dev = dev; ex->N = batch; ex->flags = flags;
     ex->in_c = net->layer_list[0].c; ex->in_h = net->layer_list[0].h; ex->in_w = net->layer_list[0].w;
     bool ok = hipStreamCreateWithFlags(&ex->own_stream, hipStreamNonBlocking) == hipSuccess
+           && hipStreamCreateWithFlags(&ex->side_stream, hipStreamNonBlocking) == hipSuccess
+           && hipEventCreateWithFlags(&ex->ev_fork, hipEventDisableTiming) == hipSuccess
+           && hipEventCreateWithFlags(&ex->ev_join, hipEventDisableTiming) == hipSuccess
            && hipMalloc(&ex->d_cand, sizeof(BBOX) * FFGPU_MAX_CAND * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_cand_key, sizeof(int) * FFGPU_MAX_CAND * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_ncand, sizeof(int) * (size_t)batch) == hipSuccess
@@ -530,6 +595,9 @@ extern "C" void ffgpu_exec_destroy(ffgpu_exec *ex)
     (void)hipFree(ex->arena); (void)hipFree(ex->d_input); (void)hipFree(ex->d_pack); (void)hipFree(ex->d_cand);
     (void)hipFree(ex->d_cand_key); (void)hipFree(ex->d_ncand); (void)hipFree(ex->d_dets);
     if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
+    if (ex->side_stream) (void)hipStreamDestroy(ex->side_stream);
+    if (ex->ev_fork) (void)hipEventDestroy(ex->ev_fork);
+    if (ex->ev_join) (void)hipEventDestroy(ex->ev_join);
     delete ex;
 }
 

@@ -169,6 +169,19 @@ def test_fused_graph_executor_boxes(F, net, frames, oracle_runs, flags):
         assert ex.kernel_count <= 140
 
 
+def test_branch_parallel_executor(F, net, frames, oracle_runs, monkeypatch):
+    """FFGPU_BRANCH=1: the first detection head as a parallel graph branch (own stream, disjoint arena)."""
+    monkeypatch.setenv("FFGPU_BRANCH", "1")
+    for flags in (0, 4):
+        with net.executor(4, flags) as ex:
+            for rep in range(3):
+                ex.forward_host(frames)
+                dets = ex.read_dets()
+                for f in range(4):
+                    boxes_match(ex.read_candidates(f), oracle_runs[f]["cand"], "cand frame %d" % f)
+                    boxes_match(ex.boxes(f, dets), oracle_runs[f]["boxes"], "boxes frame %d" % f)
+
+
 def test_compat_v6_executor(F, net, frames, orc):
     """FFGPU_COMPAT_V6 reproduces conv-v6.c's 5x5 row omission (layers 116.. and 125..)."""
     o = orc.Oracle()
