@@ -188,6 +188,7 @@ IRB_SHAPES = [  # (ic, ec, oc, stride, N, H, W, residual)
     (16, 96, 16, 1, 2, 40, 40, True), (16, 96, 24, 2, 2, 40, 40, False), (24, 136, 24, 1, 3, 20, 20, True),
     (24, 136, 48, 2, 2, 20, 20, False), (48, 224, 48, 1, 3, 10, 10, True), (8, 8, 4, 1, 1, 32, 48, False),
     (4, 8, 4, 1, 2, 16, 16, True), (12, 40, 20, 1, 1, 12, 20, True), (6, 30, 10, 2, 2, 16, 12, False),
+    (8, 32, 8, 1, 2, 13, 11, True), (16, 50, 30, 1, 1, 9, 22, True), (3, 20, 5, 2, 3, 21, 17, True), (8, 64, 16, 2, 1, 30, 26, False),
 ]
 
 
@@ -212,3 +213,12 @@ def test_irb_fused_block(env, shape):
                  out.data_ptr(), N, W, H, ic, ec, oc, stride)
     torch.cuda.synchronize()
     check(out.cpu().numpy(), ref, "irb %s" % (shape,))
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("shape", [(24, 136, 24, 1, 3, 20, 20, True), (48, 224, 48, 1, 2, 10, 10, True), (8, 48, 16, 1, 2, 40, 40, False),
+                                   (4, 24, 8, 2, 2, 48, 32, True)])
+def test_irb_wave_group_split(env, shape, G, monkeypatch):
+    """wave-autonomous fused block with the channel groups of a tile split over G waves (fixed-order LDS reduction)"""
+    monkeypatch.setenv("FFGPU_IRBW_G", str(G))
+    test_irb_fused_block(env, shape)
