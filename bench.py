@@ -246,7 +246,11 @@ def main():
     # two executors used alternately: while step i's records are gathered / copied to the host on a side stream,
     # step i+1 already runs on the compute stream (the gather is latency-bound)
     # (single GPU: nothing to hide and a second arena only dilutes the Infinity Cache -> one executor)
-    exs = [net.executor(B), net.executor(B)] if (world > 1 and not args.no_overlap) or args.overlap else [net.executor(B)]
+    # single GPU: the NMS kernel writes the records straight into a pinned host mirror (FFGPU_HOST_DETS), so the boxes
+    # are on the host when the step ends with no device-to-host copy between two graph launches
+    host_dets = world == 1 and not args.overlap
+    exs = [net.executor(B), net.executor(B)] if (world > 1 and not args.no_overlap) or args.overlap else \
+          [net.executor(B, capi.FFGPU.HOST_DETS if host_dets else 0)]
     ex = exs[0]
 
     # synthetic frames (seeded per rank); frame 0 of rank 0 is the letterboxed test.bmp so boxes can be checked
@@ -281,6 +285,12 @@ def main():
 
     def step(i):
         k = i % nex
+        if nex == 1 and world == 1:                             # one in-order stream: no events, no copies to order
+            exs[0].forward_dev(x.data_ptr(), stream.cuda_stream)
+            if not host_dets:
+                with torch.cuda.stream(stream):
+                    host[0][0].copy_(dets[0], non_blocking=True)
+            return
         with torch.cuda.stream(stream):
             stream.wait_event(ev_comm[k])                       # this executor's previous records have been shipped
             exs[k].forward_dev(x.data_ptr(), stream.cuda_stream)
@@ -292,7 +302,7 @@ def main():
                 ffdist.gather_records(dist, send[k], dst=0, out=glist)
                 if rank == 0:
                     host[k].copy_(big, non_blocking=True)       # one D2H copy for the whole job's records
-            else:
+            elif not host_dets:
                 host[k][0].copy_(dets[k], non_blocking=True)
             ev_comm[k].record(comm)
 
@@ -321,7 +331,7 @@ def main():
         fps = B * world * args.steps / dt
         ok = None
         if check is not None:
-            rec = np.frombuffer(host[last][0].numpy().tobytes(), capi.DETS_DTYPE, B)
+            rec = exs[0].dets_host() if host_dets else np.frombuffer(host[last][0].numpy().tobytes(), capi.DETS_DTYPE, B)
             got = rec[0]["box"][: rec[0]["count"]]
             ok = bool(len(got) == len(check) and all(
                 int(a["type"]) == int(b["type"]) and abs(float(a["score"]) - float(b["score"])) < 1e-4 and
@@ -334,7 +344,7 @@ def main():
             "config": {"workload": "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[3]/[4])",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "launches_per_step": ex.kernel_count, "arena_MB": round(ex.arena_bytes / 2**20, 1),
-                       "executors": nex, "gather": "overlapped with the next step on a side stream" if nex > 1 else "in line",
+                       "executors": nex, "gather": "overlapped with the next step on a side stream" if nex > 1 else ("records written to pinned host memory by the NMS kernel" if host_dets else "in line"),
                        "weights": "data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL, untimed)",
                        "boxes_match_reference_golden_frame0": ok},
         }

@@ -17,7 +17,7 @@ f32p = C.POINTER(C.c_float)
 class FFGPU:
     MAX_DET = 128
     MAX_CAND = 1024
-    KEEP_ALL, COMPAT_V6, NO_GRAPH, NO_FUSE = 1, 2, 4, 8
+    KEEP_ALL, COMPAT_V6, NO_GRAPH, NO_FUSE, HOST_DETS = 1, 2, 4, 8, 16
     K_AUTO, K_GENERIC, K_DW_STREAM, K_DW_LDS, K_PW_MFMA, K_PW_GEMM, K_PW_VALU, K_DENSE_SMALL = range(8)
 
 
@@ -62,7 +62,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_net_weights_dev", "ffgpu_net_weights_commit",
            "ffgpu_exec_create", "ffgpu_exec_destroy", "ffgpu_exec_batch", "ffgpu_exec_arena_bytes",
            "ffgpu_exec_kernel_count", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
-           "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
+           "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
            "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_membench", "ffgpu_irb_dev"]
 
 
@@ -118,6 +118,7 @@ def lib():
     L.ffgpu_exec_forward_host.argtypes = [vp, f32p]
     L.ffgpu_exec_forward_bgr_dev.argtypes = [vp, vp, i, i, f32p, f32p, vp]
     L.ffgpu_exec_dets_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+    L.ffgpu_exec_dets_host.restype = vp; L.ffgpu_exec_dets_host.argtypes = [vp]
     L.ffgpu_exec_read_dets.argtypes = [vp, vp, i]
     L.ffgpu_exec_read_layer.argtypes = [vp, i, i, f32p, sz]
     L.ffgpu_exec_profile.argtypes = [vp, vp, f32p]
@@ -316,6 +317,14 @@ class Executor:
         ptr, nbytes = C.c_void_p(), C.c_size_t()
         _check(lib().ffgpu_exec_dets_dev(self.h, C.byref(ptr), C.byref(nbytes)), "ffgpu_exec_dets_dev")
         return ptr.value, nbytes.value
+
+    def dets_host(self):
+        """numpy view of the pinned host mirror (FFGPU.HOST_DETS executors); valid after the stream is synchronised"""
+        ptr = lib().ffgpu_exec_dets_host(self.h)
+        if not ptr:
+            raise RuntimeError("ffgpu_exec_dets_host: " + last_error())
+        buf = (C.c_char * (DETS_DTYPE.itemsize * self.batch)).from_address(ptr)
+        return np.frombuffer(buf, DETS_DTYPE, self.batch)
 
     def read_dets(self):
         out = np.zeros(self.batch, DETS_DTYPE)

@@ -109,6 +109,7 @@ struct ffgpu_exec {
     BBOX  *d_cand = nullptr;
     int   *d_cand_key = nullptr, *d_ncand = nullptr;
     ffgpu_frame_dets *d_dets = nullptr;
+    ffgpu_frame_dets *h_dets = nullptr, *h_dets_dev = nullptr;   // FFGPU_HOST_DETS: pinned mirror and its device address
     int    s1 = 1, s2 = 1;
     hipStream_t own_stream = nullptr, last_stream = nullptr;
     hipStream_t side_stream = nullptr;              // second graph branch
@@ -483,7 +484,7 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
     case S_YOLO:
         return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand, s);
     case S_NMS:
-        return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->d_dets, ex->N, 0.5f, 1, ex->s1, ex->s2, s);
+        return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->d_dets, ex->h_dets_dev, ex->N, 0.5f, 1, ex->s1, ex->s2, s);
     }
     return -1;
 }
@@ -578,6 +579,11 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
            && hipMalloc(&ex->d_ncand, sizeof(int) * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess
            && hipMemset(ex->d_dets, 0, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess;
+    if (ok && (flags & FFGPU_HOST_DETS)) {
+        ok = hipHostMalloc(&ex->h_dets, sizeof(ffgpu_frame_dets) * (size_t)batch, hipHostMallocMapped) == hipSuccess
+          && hipHostGetDevicePointer((void **)&ex->h_dets_dev, ex->h_dets, 0) == hipSuccess;
+        if (ok) memset(ex->h_dets, 0, sizeof(ffgpu_frame_dets) * (size_t)batch);
+    }
     if (!ok) { ffgpu_set_error("executor buffers: %s", hipGetErrorString(hipGetLastError())); ffgpu_exec_destroy(ex); return nullptr; }
     if (plan(ex) != 0 || repack(ex, ex->own_stream) != 0 || hipStreamSynchronize(ex->own_stream) != hipSuccess) { ffgpu_exec_destroy(ex); return nullptr; }
     ex->last_stream = ex->own_stream;
@@ -594,6 +600,7 @@ extern "C" void ffgpu_exec_destroy(ffgpu_exec *ex)
     for (const Step &st : ex->steps) if (st.kind == S_TOCNHW) (void)hipFree(st.out);
     (void)hipFree(ex->arena); (void)hipFree(ex->d_input); (void)hipFree(ex->d_pack); (void)hipFree(ex->d_cand);
     (void)hipFree(ex->d_cand_key); (void)hipFree(ex->d_ncand); (void)hipFree(ex->d_dets);
+    if (ex->h_dets) (void)hipHostFree(ex->h_dets);
     if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
     if (ex->side_stream) (void)hipStreamDestroy(ex->side_stream);
     if (ex->ev_fork) (void)hipEventDestroy(ex->ev_fork);
@@ -659,12 +666,20 @@ extern "C" int ffgpu_exec_dets_dev(ffgpu_exec *ex, void **dev_ptr, size_t *bytes
     return 0;
 }
 
+extern "C" const ffgpu_frame_dets *ffgpu_exec_dets_host(ffgpu_exec *ex)
+{
+    if (!ex) { ffgpu_set_error("NULL executor"); return nullptr; }
+    if (!ex->h_dets) ffgpu_set_error("executor was not created with FFGPU_HOST_DETS");
+    return ex->h_dets;
+}
+
 extern "C" int ffgpu_exec_read_dets(ffgpu_exec *ex, ffgpu_frame_dets *host_out, int max_frames)
 {
     if (!ex || !host_out) { ffgpu_set_error("read_dets: NULL argument"); return -1; }
     const int n = std::min(max_frames, ex->N);
     FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
-    FFGPU_CHECK(hipMemcpy(host_out, ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)n, hipMemcpyDeviceToHost));
+    if (ex->h_dets) memcpy(host_out, ex->h_dets, sizeof(ffgpu_frame_dets) * (size_t)n);
+    else FFGPU_CHECK(hipMemcpy(host_out, ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)n, hipMemcpyDeviceToHost));
     return n;
 }
 

@@ -202,8 +202,10 @@ __global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *
 // (score desc, emission key asc) with a bitonic sort in LDS -- the key makes the
 // order total where qsort's is unspecified -- then suppressed greedily per class
 // with inter/min(area) (or IoU) > thresh, compacted and rescaled by s1/s2.
+// dets_host (may be NULL): pinned host mirror of the records, written by the same threads (FFGPU_HOST_DETS) so a
+// single-GPU consumer needs no device-to-host copy after the forward
 __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_key, const int *ncand,
-                                             ffgpu_frame_dets *dets, float thresh, int use_min, int s1, int s2)
+                                             ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, float thresh, int use_min, int s1, int s2)
 {
 #pragma clang fp contract(off)
     __shared__ float s_score[FFGPU_MAX_CAND];
@@ -260,25 +262,37 @@ __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_k
         }
         __syncthreads();
     }
+    // survivors in score order -> record slots (one thread walks the list, every thread writes one slot)
+    __shared__ short s_keep[FFGPU_MAX_DET];
+    __shared__ int s_nkeep, s_clipped;
     if (tid == 0) {
         int keep = 0, clipped = 0;
         for (int i = 0; i < m; i++) {
             if (!s_alive[i]) continue;
             if (keep == FFGPU_MAX_DET) { clipped = 1; break; }
-            const BBOX b = c[s_idx[i]];
-            BBOX r;
+            s_keep[keep++] = s_idx[i];
+        }
+        s_nkeep = keep; s_clipped = clipped;
+    }
+    __syncthreads();
+    ffgpu_frame_dets *outs[2] = { out, dets_host ? dets_host + n : nullptr };
+    for (int i = tid; i < FFGPU_MAX_DET; i += blockDim.x) {
+        BBOX r = { 0, 0.f, 0.f, 0.f, 0.f, 0.f };                   // reference zeroes the tail (ffcnn.c:333)
+        if (i < s_nkeep) {
+            const BBOX b = c[s_keep[i]];
             r.type = b.type; r.score = b.score;
             r.x1 = b.x1 * s1 / s2; r.y1 = b.y1 * s1 / s2;
             r.x2 = b.x2 * s1 / s2; r.y2 = b.y2 * s1 / s2;
-            out->box[keep++] = r;
         }
-        out->count = keep;
-        out->ncand = total;
-        out->overflow = (total > FFGPU_MAX_CAND) | clipped;
-        out->reserved = 0;
-        const BBOX z = { 0, 0.f, 0.f, 0.f, 0.f, 0.f };
-        for (int i = keep; i < FFGPU_MAX_DET; i++) out->box[i] = z;     // reference zeroes the tail (ffcnn.c:333)
+        for (int k = 0; k < 2; k++) if (outs[k]) outs[k]->box[i] = r;
     }
+    if (tid == 0)
+        for (int k = 0; k < 2; k++) if (outs[k]) {
+            outs[k]->count = s_nkeep;
+            outs[k]->ncand = total;
+            outs[k]->overflow = (total > FFGPU_MAX_CAND) | s_clipped;
+            outs[k]->reserved = 0;
+        }
 }
 
 // ---------------------------------------------------------------------------
@@ -347,10 +361,10 @@ int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand,
     return 0;
 }
 
-int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, const int *ncand, ffgpu_frame_dets *dets, int N,
+int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, const int *ncand, ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, int N,
                      float thresh, int use_min, int s1, int s2, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_nms, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, dets, thresh, use_min, s1, s2);
+    hipLaunchKernelGGL(k_nms, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, dets, dets_host, thresh, use_min, s1, s2);
     LAUNCH_OK("nms");
     return 0;
 }

@@ -48,6 +48,8 @@ typedef struct ffgpu_exec ffgpu_exec;     /* a planned executor: one NET x one b
 #define FFGPU_COMPAT_V6  2    /* reproduce conv-v6.c:422-441 (5x5 depthwise row oh-2 defect) */
 #define FFGPU_NO_GRAPH   4    /* launch kernels eagerly instead of replaying a HIP graph     */
 #define FFGPU_NO_FUSE    8    /* one kernel per reference layer (no cross-layer fusion)      */
+#define FFGPU_HOST_DETS  16   /* the NMS kernel also writes the records to a pinned host     */
+                              /* mirror (ffgpu_exec_dets_host): no D2H copy after a forward   */
 
 /* ---- process / device --------------------------------------------------- */
 int         ffgpu_device_count(void);
@@ -91,6 +93,9 @@ int ffgpu_exec_forward_bgr_dev(ffgpu_exec *ex, const unsigned char *d_bgr, int w
 /* Device address of the batch's ffgpu_frame_dets[batch] (valid after the
  * forward enqueued on the same stream completes). */
 int ffgpu_exec_dets_dev(ffgpu_exec *ex, void **dev_ptr, size_t *bytes);
+/* FFGPU_HOST_DETS executors: the pinned host mirror of the same `batch` records (valid once the
+ * forward's stream has been synchronised); NULL + error otherwise. */
+const ffgpu_frame_dets *ffgpu_exec_dets_host(ffgpu_exec *ex);
 /* Synchronise the executor's last stream and copy the records to the host. */
 int ffgpu_exec_read_dets(ffgpu_exec *ex, ffgpu_frame_dets *host_out, int max_frames);
 

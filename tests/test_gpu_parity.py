@@ -169,6 +169,21 @@ def test_fused_graph_executor_boxes(F, net, frames, oracle_runs, flags):
         assert ex.kernel_count <= 140
 
 
+def test_host_mirror_of_records(F, net, frames, oracle_runs):
+    """FFGPU_HOST_DETS: the NMS kernel's pinned host mirror holds the same records as the device buffer."""
+    with net.executor(4, F.FFGPU.HOST_DETS) as ex:
+        for rep in range(2):
+            ex.forward_host(frames)
+            dets = ex.read_dets()                       # synchronises, reads the mirror
+            mirror = ex.dets_host()
+            assert mirror.tobytes() == dets.tobytes()
+            for f in range(4):
+                boxes_match(ex.boxes(f, dets), oracle_runs[f]["boxes"], "boxes frame %d" % f)
+    with net.executor(1, 0) as ex:
+        with pytest.raises(RuntimeError, match="HOST_DETS"):
+            ex.dets_host()
+
+
 def test_branch_parallel_executor(F, net, frames, oracle_runs, monkeypatch):
     """FFGPU_BRANCH=1: the first detection head as a parallel graph branch (own stream, disjoint arena)."""
     monkeypatch.setenv("FFGPU_BRANCH", "1")
