@@ -57,6 +57,7 @@ int    ffgpu_pw_pack(const ConvDesc &d, float *pk, hipStream_t s);
 int         ffgpu_launch_conv(const ConvDesc &d, int variant, hipStream_t s);
 const char *ffgpu_conv_kernel_name(const ConvDesc &d, int variant);
 int ffgpu_launch_pool(const float *in, float *out, int N, int c, int w, int h, int fs, int stride, int is_max, hipStream_t s);
+int ffgpu_launch_spp(const float *in, float *const out[3], const int fs[3], int n, long planes, int w, int h, hipStream_t s);
 int ffgpu_launch_upsample(const float *in, float *out, long planes, int w, int h, int stride, hipStream_t s);
 int ffgpu_launch_add_act(const float *a, const float *b, float *out, long n, int act, hipStream_t s);
 int ffgpu_launch_copy(const float *src, float *dst, long n, hipStream_t s);

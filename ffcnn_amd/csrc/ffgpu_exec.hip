@@ -72,6 +72,8 @@ struct Step {
     int      w, h, c, fs, stride, flag;
     YoloHead head;
     IrbDesc  irb;            // S_IRB: fused expand -> depthwise -> project [+ shortcut]
+    float   *out2[2];        // S_POOL: further stride-1 max pools of the same tensor merged into this launch (fs2[k] != 0)
+    int      fs2[2];
     int      lane;           // 0: main stream, 1: side stream (a detection head that runs beside the rest of the net)
 };
 
@@ -436,6 +438,21 @@ static int plan(ffgpu_exec *ex)
         }
     }
     if (bad_chain) { ffgpu_set_error("a layer consumes the (non-existent) output of a yolo head"); return -1; }
+    // stride-1 max pools of one tensor that follow each other (the routes between them are aliases: an SPP block)
+    // become one launch
+    if (fuse) {
+        for (size_t i = 0; i + 1 < S.size(); i++) {
+            Step &a = S[i];
+            if (a.kind != S_POOL || !a.flag || a.stride != 1 || a.in_is_input || (long)a.w * a.h > 8192) continue;
+            int k = 0;
+            while (k < 2 && i + 1 < S.size()) {
+                const Step &b = S[i + 1];
+                if (b.kind != S_POOL || !b.flag || b.stride != 1 || b.in_is_input || b.a != a.a || b.c != a.c || b.w != a.w || b.h != a.h) break;
+                a.out2[k] = b.out; a.fs2[k] = b.fs; k++;
+                S.erase(S.begin() + i + 1);
+            }
+        }
+    }
     { Step nm{}; nm.kind = S_NMS; nm.layer = -1; nm.ltype = LAYER_TYPE_YOLO; S.push_back(nm); }
     for (Step &st : S) st.lane = (ex->side_lo >= 0 && st.layer >= ex->side_lo && st.layer <= ex->side_hi) ? 1 : 0;
     ex->kernel_count = (int)S.size();
@@ -464,6 +481,11 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
         if (st.in_is_input) d.in = d_frames;
         return ffgpu_launch_conv(d, FFGPU_K_AUTO, s); }
     case S_POOL:
+        if (st.fs2[0]) {
+            float *const outs[3] = { st.out, st.out2[0], st.out2[1] };
+            const int fss[3] = { st.fs, st.fs2[0], st.fs2[1] };
+            return ffgpu_launch_spp(st.a, outs, fss, st.fs2[1] ? 3 : 2, (long)ex->N * st.c, st.w, st.h, s);
+        }
         return ffgpu_launch_pool(st.in_is_input ? d_frames : st.a, st.out, ex->N, st.c, st.w, st.h, st.fs, st.stride, st.flag, s);
     case S_UPSAMPLE:
         return ffgpu_launch_upsample(st.in_is_input ? d_frames : st.a, st.out, (long)ex->N * st.c, st.w, st.h, st.stride, s);

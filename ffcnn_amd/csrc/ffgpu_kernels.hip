@@ -90,6 +90,65 @@ __global__ void k_pool(const float *in, float *out, long planes, int w, int h, i
     }
 }
 
+// several stride-1 max pools of ONE tensor (the SPP block of a yolo cfg: 3x3, 5x5, 9x9 of the same 10x10 planes) in one
+// launch: a plane is staged in LDS once and every window size is read from there (same clipping as k_pool)
+struct SppP { const float *in; float *out[3]; int fs[3]; int n; long planes; int w, h; int cascade; };
+
+// cascade != 0 (odd, ascending sizes): max over a (2a+1) window of the max over a (2b+1) window is the max over the
+// (2(a+b)+1) window -- also with windows clipped to the plane -- so size k is computed from the result of size k-1
+// with a small separable (row pass, column pass) filter: 3x3, 5x5, 9x9 cost 3+3, 3+3, 5+5 LDS reads per pixel.
+__global__ void __launch_bounds__(256) k_spp(SppP p)
+{
+    extern __shared__ float spp_s[];
+    const int hw = p.w * p.h;
+    constexpr int NP = 2;                                       // planes per workgroup trip
+    float *cur = spp_s, *tmp = spp_s + NP * hw;
+    for (long pl0 = (long)blockIdx.x * NP; pl0 < p.planes; pl0 += (long)gridDim.x * NP) {
+        const int np = (int)min((long)NP, p.planes - pl0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < np * hw; i += blockDim.x) cur[i] = p.in[pl0 * hw + i];
+        __syncthreads();
+        if (!p.cascade) {
+            for (int i = threadIdx.x; i < np * hw; i += blockDim.x) {
+                const int q = i / hw, r = i - q * hw, oy = r / p.w, ox = r - oy * p.w;
+                for (int k = 0; k < p.n; k++) {
+                    const int fs = p.fs[k];
+                    int x0 = ox - (fs - 1) / 2, y0 = oy - (fs - 1) / 2;
+                    const int x1 = min(x0 + fs, p.w), y1 = min(y0 + fs, p.h);
+                    x0 = max(x0, 0); y0 = max(y0, 0);
+                    float v = cur[q * hw + y0 * p.w + x0];
+                    for (int y = y0; y < y1; y++)
+                        for (int x = x0; x < x1; x++) { const float t = cur[q * hw + y * p.w + x]; v = v < t ? t : v; }
+                    p.out[k][pl0 * hw + i] = v;
+                }
+            }
+            continue;
+        }
+        int prev = 1;
+        for (int k = 0; k < p.n; k++) {
+            const int a = (p.fs[k] - prev) / 2;                 // half width of the incremental window
+            for (int i = threadIdx.x; i < np * hw; i += blockDim.x) {
+                const int q = i / hw, r = i - q * hw, oy = r / p.w, ox = r - oy * p.w;
+                const float *row = cur + q * hw + oy * p.w;
+                float v = row[ox];
+                for (int x = max(ox - a, 0); x <= min(ox + a, p.w - 1); x++) v = v < row[x] ? row[x] : v;
+                tmp[i] = v;
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < np * hw; i += blockDim.x) {
+                const int q = i / hw, r = i - q * hw, oy = r / p.w, ox = r - oy * p.w;
+                const float *col = tmp + q * hw + ox;
+                float v = col[oy * p.w];
+                for (int y = max(oy - a, 0); y <= min(oy + a, p.h - 1); y++) v = v < col[y * p.w] ? col[y * p.w] : v;
+                p.out[k][pl0 * hw + i] = v;
+                cur[i] = v;                                     // each thread rewrites the pixels it owns in both passes
+            }
+            __syncthreads();
+            prev = p.fs[k];
+        }
+    }
+}
+
 __global__ void k_upsample(const float *in, float *out, long planes, int w, int h, int stride)
 {
     const int ow = w * stride, oh = h * stride;
@@ -318,6 +377,18 @@ int ffgpu_launch_pool(const float *in, float *out, int N, int c, int w, int h, i
     const long planes = (long)N * c, total = planes * (h / stride) * (w / stride);
     hipLaunchKernelGGL(k_pool, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, planes, w, h, fs, stride, is_max);
     LAUNCH_OK("pool");
+    return 0;
+}
+
+int ffgpu_launch_spp(const float *in, float *const out[3], const int fs[3], int n, long planes, int w, int h, hipStream_t s)
+{
+    if (n < 1 || n > 3 || (long)w * h > 8192) { ffgpu_set_error("spp: bad pool count / plane size"); return -1; }
+    SppP p; p.in = in; p.n = n; p.planes = planes; p.w = w; p.h = h;
+    for (int k = 0; k < 3; k++) { p.out[k] = k < n ? out[k] : nullptr; p.fs[k] = k < n ? fs[k] : 1; }
+    p.cascade = 1;
+    for (int k = 0, prev = 1; k < n; prev = fs[k], k++) if (!(fs[k] & 1) || fs[k] <= prev) p.cascade = 0;
+    hipLaunchKernelGGL(k_spp, dim3((unsigned)std::min((planes + 1) / 2, 4096L)), dim3(256), (size_t)4 * w * h * sizeof(float), s, p);
+    LAUNCH_OK("spp");
     return 0;
 }
 
