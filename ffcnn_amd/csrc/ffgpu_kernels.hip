@@ -221,23 +221,43 @@ __global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *
     const int cells = hd.w * hd.h;
     const long total = (long)N * 3 * cells;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int cell = (int)(gid % cells);
-    const int k = (int)((gid / cells) % 3);
-    const int n = (int)(gid / (3L * cells));
+    const int lane = threadIdx.x & 63;
+    const long gidc = min(gid, total - 1);
+    const int cell = (int)(gidc % cells);
+    const int k = (int)((gidc / cells) % 3);
+    const int n = (int)(gidc / (3L * cells));
     const int j = cell % hd.w, i = cell / hd.w;
     const long cs = (long)N * cells;                                  // CNHW channel stride
     const float *p = hd.in + (long)k * (5 + hd.classes) * cs + (long)n * cells + cell;
     const float bs = p[4 * cs];
     // conf = 1 / (1 + e^-bs (1 + e^-cs)) <= 1 / (1 + e^-bs): cells whose objectness alone cannot reach the
     // threshold (almost all of them) skip the 80-class scan.  0.1 % slack keeps the shortcut rounding-proof.
-    if (1.0f / (1.0f + __expf(-bs)) < hd.thresh * 0.999f) return;
-    float cs_best = p[5 * cs];
+    const bool pass = gid < total && !(1.0f / (1.0f + __expf(-bs)) < hd.thresh * 0.999f);
+    // class scan of a passing cell: the WAVE reads its scores (lane l -> classes l, l + 64, ...) and reduces to the
+    // first maximum (the reference's `if (best < v)` scan, ffcnn.c:452-456) -- one lane walking 80 strided loads
+    // alone set the run time of the whole kernel
+    float cs_best = 0.f;
     int best = 0;
-    for (int l = 1; l < hd.classes; l++) {
-        const float v = p[(5 + l) * cs];
-        if (cs_best < v) { cs_best = v; best = l; }
+    for (unsigned long long todo = __ballot(pass); todo; todo &= todo - 1) {
+        const int src = __ffsll((long long)todo) - 1;
+        const long g = gid - lane + src;                              // that lane's (frame, anchor, cell)
+        const int c2 = (int)(g % cells), k2 = (int)((g / cells) % 3), n2 = (int)(g / (3L * cells));
+        const float *q = hd.in + (long)k2 * (5 + hd.classes) * cs + (long)n2 * cells + c2;
+        float v = -3.0e38f;
+        int vi = 1 << 30;
+        for (int l = lane; l < hd.classes; l += 64) {
+            const float t = q[(5 + l) * cs];
+            if (v < t) { v = t; vi = l; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v, off);
+            const int oi = __shfl_xor(vi, off);
+            if (v < ov || (v == ov && oi < vi)) { v = ov; vi = oi; }
+        }
+        if (lane == src) { cs_best = v; best = vi; }
     }
+    if (!pass) return;
     const float conf = 1.0f / ((1.0f + (float)exp((double)-bs) * (1.0f + (float)exp((double)-cs_best))));
     if (!(conf >= hd.thresh)) return;
     const float tx = p[0], ty = p[cs], tw = p[2 * cs], th = p[3 * cs];
@@ -335,7 +355,11 @@ __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_k
     }
     __syncthreads();
     ffgpu_frame_dets *outs[2] = { out, dets_host ? dets_host + n : nullptr };
-    for (int i = tid; i < FFGPU_MAX_DET; i += blockDim.x) {
+    // slots at or beyond both the previous and the new count are zero already (both copies start zeroed and are only
+    // ever written here): the mirror, which sits across PCIe, is touched only where it changes
+    const int nwrite = max(s_nkeep, min(max(out->count, 0), FFGPU_MAX_DET));
+    __syncthreads();                                               // every thread has read the old count
+    for (int i = tid; i < nwrite; i += blockDim.x) {
         BBOX r = { 0, 0.f, 0.f, 0.f, 0.f, 0.f };                   // reference zeroes the tail (ffcnn.c:333)
         if (i < s_nkeep) {
             const BBOX b = c[s_keep[i]];
