@@ -161,6 +161,23 @@ __global__ void k_upsample(const float *in, float *out, long planes, int w, int 
     }
 }
 
+// the same with one thread per INPUT element and 32-bit index arithmetic (the 64-bit divisions above cost more than
+// the memory traffic on the small planes a yolo cfg upsamples); m_w / m_h = ceil(2^32 / w), ceil(2^32 / h)
+__global__ void __launch_bounds__(256) k_upsample32(const float *in, float *out, unsigned n_in, int w, int h, int stride, unsigned m_w, unsigned m_h)
+{
+    const int ow = w * stride;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n_in; idx += gridDim.x * blockDim.x) {
+        const unsigned t = m_w ? __umulhi(idx, m_w) : idx;             // idx / w
+        const unsigned x = idx - t * w;
+        const unsigned pl = m_h ? __umulhi(t, m_h) : t;                // t / h
+        const unsigned y = t - pl * h;
+        const float v = in[idx];
+        float *o = out + ((size_t)pl * h * stride + y * stride) * ow + x * stride;
+        for (int dy = 0; dy < stride; dy++)
+            for (int dx = 0; dx < stride; dx++) o[dy * ow + dx] = v;
+    }
+}
+
 // out = act(a + b), flat (ffcnn.c:418-423); 16-byte lanes with a scalar tail
 __global__ void k_add_act(const float *a, const float *b, float *out, long n, int act)
 {
@@ -418,7 +435,13 @@ int ffgpu_launch_spp(const float *in, float *const out[3], const int fs[3], int 
 
 int ffgpu_launch_upsample(const float *in, float *out, long planes, int w, int h, int stride, hipStream_t s)
 {
-    const long total = planes * h * stride * w * stride;
+    const long total = planes * h * stride * w * stride, n_in = planes * h * w;
+    if (n_in * std::max(w, h) < (1L << 32) && total < (1L << 32)) {      // umulhi division exact, offsets fit 32 bits
+        auto magic = [](long dv) { return dv == 1 ? 0u : (unsigned)(((1ULL << 32) + (unsigned long long)dv - 1) / (unsigned long long)dv); };
+        hipLaunchKernelGGL(k_upsample32, dim3(grid_for(n_in, 256)), dim3(256), 0, s, in, out, (unsigned)n_in, w, h, stride, magic(w), magic(h));
+        LAUNCH_OK("upsample");
+        return 0;
+    }
     hipLaunchKernelGGL(k_upsample, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, planes, w, h, stride);
     LAUNCH_OK("upsample");
     return 0;
