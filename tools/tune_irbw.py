@@ -26,15 +26,18 @@ for si, (ic, ec, oc, s, HW, res) in enumerate(SHAPES):
                             N, HW, HW, ic, ec, oc, s, warmup=2, iters=10)
     results = []
     tiles = [(0, 0)] + [(a, b) for a in (1, 2, 3, 4, 5) for b in (1, 2, 3, 4, 5, 8) if a * b <= 16 and a * b >= 6 and (a - 1) * 4 < OH]
-    for (tq, th), G in itertools.product(tiles, (1, 2, 3, 4, 6, 7, 8)):
+    quick = os.environ.get("TUNE_QUICK")
+    if quick:
+        tiles = [(0, 0)]
+    for (tq, th), G, big in itertools.product(tiles, (1, 2, 3, 4, 6, 7, 8), (0, 1)):
         if G > (ec + 15) // 16:
             continue
-        os.environ.update(FFGPU_IRBW_G=str(G), FFGPU_IRBW_TWQ=str(tq), FFGPU_IRBW_TH=str(th))
+        os.environ.update(FFGPU_IRBW_G=str(G), FFGPU_IRBW_TWQ=str(tq), FFGPU_IRBW_TH=str(th), FFGPU_IRBW_BIG=str(big))
         try:
-            results.append((run(), tq, th, G))
+            results.append((run(), tq, th, G * 10 + big))
         except RuntimeError:
             continue
-    for k in ("FFGPU_IRBW_G", "FFGPU_IRBW_TWQ", "FFGPU_IRBW_TH"):
+    for k in ("FFGPU_IRBW_G", "FFGPU_IRBW_TWQ", "FFGPU_IRBW_TH", "FFGPU_IRBW_BIG"):
         os.environ.pop(k, None)
     auto = run()
     os.environ["FFGPU_NO_IRBW"] = "1"
@@ -42,4 +45,4 @@ for si, (ic, ec, oc, s, HW, res) in enumerate(SHAPES):
     os.environ.pop("FFGPU_NO_IRBW")
     results.sort()
     print("block %2d  %3dx%-3d %2d->%3d->%2d s%d: auto %.1f us (workgroup kernel %.1f); best: %s" %
-          (si, HW, HW, ic, ec, oc, s, auto, old, "  ".join("%dx%d/G%d %.1f" % (4 * tq, th, G, us) for us, tq, th, G in results[:8])))
+          (si, HW, HW, ic, ec, oc, s, auto, old, "  ".join("%dx%d/G%d%s %.1f" % (4 * tq, th, G // 10, "b" if G % 10 else "", us) for us, tq, th, G in results[:10])))
