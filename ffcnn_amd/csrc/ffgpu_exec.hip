@@ -252,9 +252,9 @@ static int plan(ffgpu_exec *ex)
     // 10x10 kernels are latency-bound and hide under the other branch).  Their tensors must then not share arena
     // space: every tensor born after the fork stays live to the end.
     ex->side_lo = ex->side_hi = -1;
-    // MEASURED (r01): 1.5 % SLOWER than the single chain on a 64-frame batch (the graph's cross-branch dependencies cost
-    // more than the 10x10 kernels' idle time), so it is opt-in: FFGPU_BRANCH=1.
-    const bool branch = getenv("FFGPU_BRANCH") && atoi(getenv("FFGPU_BRANCH"));
+    // MEASURED (r01): 1.5 % slower than the single chain while the head kernels were slow, 2 % FASTER once they were
+    // latency-sized (0.766 vs 0.782 ms per 64-frame batch) -> on by default; FFGPU_BRANCH=0 turns it off.
+    const bool branch = !getenv("FFGPU_BRANCH") || atoi(getenv("FFGPU_BRANCH"));
     if (fuse && branch) {
         for (int y = 0; y + 1 < L; y++) {
             if (ll[y].type != LAYER_TYPE_YOLO || ll[y + 1].type != LAYER_TYPE_ROUTE || ll[y + 1].depend_num != 1) continue;

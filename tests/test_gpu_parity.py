@@ -185,9 +185,9 @@ def test_host_mirror_of_records(F, net, frames, oracle_runs):
 
 
 def test_branch_parallel_executor(F, net, frames, oracle_runs, monkeypatch):
-    """FFGPU_BRANCH=1: the first detection head as a parallel graph branch (own stream, disjoint arena)."""
-    monkeypatch.setenv("FFGPU_BRANCH", "1")
-    for flags in (0, 4):
+    """the first detection head as a parallel graph branch (own stream, disjoint arena) and with FFGPU_BRANCH=0"""
+    for flags, br in ((0, "1"), (4, "1"), (0, "0")):
+        monkeypatch.setenv("FFGPU_BRANCH", br)
         with net.executor(4, flags) as ex:
             for rep in range(3):
                 ex.forward_host(frames)
