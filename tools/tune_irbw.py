@@ -7,7 +7,7 @@ from ffcnn_amd import capi
 
 SHAPES = [(4, 24, 8, 2, 160, False), (8, 32, 8, 1, 80, True), (8, 32, 8, 2, 80, False),
           (8, 48, 8, 1, 40, True), (16, 96, 16, 1, 40, True), (16, 96, 24, 2, 40, False), (24, 136, 24, 1, 20, True),
-          (48, 224, 48, 1, 10, True)]
+          (48, 224, 48, 1, 10, True), (24, 136, 48, 2, 20, False)]
 N = 64
 only = [int(a) for a in sys.argv[1:]]
 for si, (ic, ec, oc, s, HW, res) in enumerate(SHAPES):
