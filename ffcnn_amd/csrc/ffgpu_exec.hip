@@ -112,6 +112,7 @@ struct ffgpu_exec {
     int   *d_cand_key = nullptr, *d_ncand = nullptr;
     ffgpu_frame_dets *d_dets = nullptr;
     ffgpu_frame_dets *h_dets = nullptr, *h_dets_dev = nullptr;   // FFGPU_HOST_DETS: pinned mirror and its device address
+    ffgpu_frame_dets *ring = nullptr; int ring_slots = 0; int *d_ringctr = nullptr;   // ffgpu_exec_set_ring
     int    s1 = 1, s2 = 1;
     hipStream_t own_stream = nullptr, last_stream = nullptr;
     hipStream_t side_stream = nullptr;              // second graph branch
@@ -474,8 +475,7 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
 {
     switch (st.kind) {
     case S_CLEAR:
-        FFGPU_CHECK(hipMemsetAsync(ex->d_ncand, 0, sizeof(int) * ex->N, s));
-        return 0;
+        return ffgpu_launch_clear(ex->d_ncand, ex->N, ex->ring ? ex->d_ringctr : nullptr, s);
     case S_CONV: {
         ConvDesc d = st.conv;
         if (st.in_is_input) d.in = d_frames;
@@ -506,7 +506,7 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
     case S_YOLO:
         return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand, s);
     case S_NMS:
-        return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->d_dets, ex->h_dets_dev, ex->N, 0.5f, 1, ex->s1, ex->s2, s);
+        return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->d_dets, ex->h_dets_dev, ex->ring, ex->ring_slots, ex->d_ringctr, ex->N, 0.5f, 1, ex->s1, ex->s2, s);
     }
     return -1;
 }
@@ -600,6 +600,7 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
            && hipMalloc(&ex->d_cand_key, sizeof(int) * FFGPU_MAX_CAND * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_ncand, sizeof(int) * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess
+           && hipMalloc(&ex->d_ringctr, sizeof(int)) == hipSuccess && hipMemset(ex->d_ringctr, 0, sizeof(int)) == hipSuccess
            && hipMemset(ex->d_dets, 0, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess;
     if (ok && (flags & FFGPU_HOST_DETS)) {
         ok = hipHostMalloc(&ex->h_dets, sizeof(ffgpu_frame_dets) * (size_t)batch, hipHostMallocMapped) == hipSuccess
@@ -623,6 +624,7 @@ extern "C" void ffgpu_exec_destroy(ffgpu_exec *ex)
     (void)hipFree(ex->arena); (void)hipFree(ex->d_input); (void)hipFree(ex->d_pack); (void)hipFree(ex->d_cand);
     (void)hipFree(ex->d_cand_key); (void)hipFree(ex->d_ncand); (void)hipFree(ex->d_dets);
     if (ex->h_dets) (void)hipHostFree(ex->h_dets);
+    (void)hipFree(ex->d_ringctr);
     if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
     if (ex->side_stream) (void)hipStreamDestroy(ex->side_stream);
     if (ex->ev_fork) (void)hipEventDestroy(ex->ev_fork);
@@ -685,6 +687,17 @@ extern "C" int ffgpu_exec_dets_dev(ffgpu_exec *ex, void **dev_ptr, size_t *bytes
     if (!ex) { ffgpu_set_error("NULL executor"); return -1; }
     if (dev_ptr) *dev_ptr = ex->d_dets;
     if (bytes) *bytes = sizeof(ffgpu_frame_dets) * (size_t)ex->N;
+    return 0;
+}
+
+extern "C" int ffgpu_exec_set_ring(ffgpu_exec *ex, void *dev_ring, int slots)
+{
+    if (!ex || (dev_ring && slots < 1)) { ffgpu_set_error("set_ring: bad arguments"); return -1; }
+    FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
+    for (auto &g : ex->graphs) (void)hipGraphExecDestroy(g.second);      // the ring pointer is a kernel argument of the graphs
+    ex->graphs.clear();
+    ex->ring = (ffgpu_frame_dets *)dev_ring; ex->ring_slots = dev_ring ? slots : 0;
+    FFGPU_CHECK(hipMemset(ex->d_ringctr, 0, sizeof(int)));
     return 0;
 }
 

@@ -300,8 +300,11 @@ __global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *
 // with inter/min(area) (or IoU) > thresh, compacted and rescaled by s1/s2.
 // dets_host (may be NULL): pinned host mirror of the records, written by the same threads (FFGPU_HOST_DETS) so a
 // single-GPU consumer needs no device-to-host copy after the forward
+// ring (may be NULL): caller-owned device ring of ring_slots x N records; forward number *ring_ctr (counted by k_clear at
+// the start of the forward) goes to slot (*ring_ctr - 1) % ring_slots -- the multi-GPU job gathers whole groups of slots
 __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_key, const int *ncand,
-                                             ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, float thresh, int use_min, int s1, int s2)
+                                             ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, ffgpu_frame_dets *ring, int ring_slots,
+                                             const int *ring_ctr, float thresh, int use_min, int s1, int s2)
 {
 #pragma clang fp contract(off)
     __shared__ float s_score[FFGPU_MAX_CAND];
@@ -371,12 +374,14 @@ __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_k
         s_nkeep = keep; s_clipped = clipped;
     }
     __syncthreads();
-    ffgpu_frame_dets *outs[2] = { out, dets_host ? dets_host + n : nullptr };
-    // slots at or beyond both the previous and the new count are zero already (both copies start zeroed and are only
-    // ever written here): the mirror, which sits across PCIe, is touched only where it changes
+    ffgpu_frame_dets *outs[3] = { out, dets_host ? dets_host + n : nullptr, nullptr };
+    if (ring) outs[2] = ring + (size_t)((unsigned)(*ring_ctr - 1) % (unsigned)ring_slots) * gridDim.x + n;
+    // slots at or beyond both the previous and the new count are zero already in the record and its host mirror (both
+    // start zeroed and are only ever written here): the mirror, which sits across PCIe, is touched only where it
+    // changes.  A ring slot last held some older forward's record, so it is written in full.
     const int nwrite = max(s_nkeep, min(max(out->count, 0), FFGPU_MAX_DET));
     __syncthreads();                                               // every thread has read the old count
-    for (int i = tid; i < nwrite; i += blockDim.x) {
+    for (int i = tid; i < FFGPU_MAX_DET; i += blockDim.x) {
         BBOX r = { 0, 0.f, 0.f, 0.f, 0.f, 0.f };                   // reference zeroes the tail (ffcnn.c:333)
         if (i < s_nkeep) {
             const BBOX b = c[s_keep[i]];
@@ -384,15 +389,23 @@ __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_k
             r.x1 = b.x1 * s1 / s2; r.y1 = b.y1 * s1 / s2;
             r.x2 = b.x2 * s1 / s2; r.y2 = b.y2 * s1 / s2;
         }
-        for (int k = 0; k < 2; k++) if (outs[k]) outs[k]->box[i] = r;
+        if (i < nwrite) { outs[0]->box[i] = r; if (outs[1]) outs[1]->box[i] = r; }
+        if (outs[2]) outs[2]->box[i] = r;
     }
     if (tid == 0)
-        for (int k = 0; k < 2; k++) if (outs[k]) {
+        for (int k = 0; k < 3; k++) if (outs[k]) {
             outs[k]->count = s_nkeep;
             outs[k]->ncand = total;
             outs[k]->overflow = (total > FFGPU_MAX_CAND) | s_clipped;
             outs[k]->reserved = 0;
         }
+}
+
+// start of a forward: no candidates yet; one more forward for the record ring
+__global__ void k_clear(int *ncand, int N, int *ring_ctr)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) ncand[i] = 0;
+    if (ring_ctr && blockIdx.x == 0 && threadIdx.x == 0) *ring_ctr += 1;
 }
 
 // ---------------------------------------------------------------------------
@@ -479,11 +492,19 @@ int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand,
     return 0;
 }
 
-int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, const int *ncand, ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, int N,
+int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, const int *ncand, ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
+                     ffgpu_frame_dets *ring, int ring_slots, const int *ring_ctr, int N,
                      float thresh, int use_min, int s1, int s2, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_nms, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, dets, dets_host, thresh, use_min, s1, s2);
+    hipLaunchKernelGGL(k_nms, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, dets, dets_host, ring, ring_slots, ring_ctr, thresh, use_min, s1, s2);
     LAUNCH_OK("nms");
+    return 0;
+}
+
+int ffgpu_launch_clear(int *ncand, int N, int *ring_ctr, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_clear, dim3((N + 255) / 256), dim3(256), 0, s, ncand, N, ring_ctr);
+    LAUNCH_OK("clear");
     return 0;
 }
 

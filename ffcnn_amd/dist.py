@@ -28,9 +28,9 @@ def broadcast_weights(dist, weights, src=0):
 def gather_records(dist, local, dst=0, out=None):
     """Gather equal-sized uint8 record tensors to `dst`.  Returns the list of per-rank tensors on dst,
     None elsewhere.  `out` (a list of preallocated tensors) avoids allocations in a timed loop."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return [local]
+    world = dist.get_world_size()
     rank = dist.get_rank()
     if rank == dst and out is None:
         out = [local.new_empty(local.shape) for _ in range(world)]

@@ -96,6 +96,11 @@ int ffgpu_exec_dets_dev(ffgpu_exec *ex, void **dev_ptr, size_t *bytes);
 /* FFGPU_HOST_DETS executors: the pinned host mirror of the same `batch` records (valid once the
  * forward's stream has been synchronised); NULL + error otherwise. */
 const ffgpu_frame_dets *ffgpu_exec_dets_host(ffgpu_exec *ex);
+/* Record ring for the multi-GPU gather: from now on forward number k (k = 0, 1, ... counted on the device) ALSO
+ * writes its `batch` records into slot k % slots of the caller-owned device buffer `dev_ring` (slots x batch
+ * records), so groups of steps travel in one collective with no copy between graph launches.  Calling it again
+ * (or with NULL) restarts the count / detaches.  Synchronises the executor's stream. */
+int ffgpu_exec_set_ring(ffgpu_exec *ex, void *dev_ring, int slots);
 /* Synchronise the executor's last stream and copy the records to the host. */
 int ffgpu_exec_read_dets(ffgpu_exec *ex, ffgpu_frame_dets *host_out, int max_frames);
 

@@ -184,6 +184,26 @@ def test_host_mirror_of_records(F, net, frames, oracle_runs):
             ex.dets_host()
 
 
+def test_record_ring(F, net, frames, oracle_runs):
+    """ffgpu_exec_set_ring: forward k also lands in slot k % slots of a caller-owned device ring"""
+    import torch
+    with net.executor(4, 0) as ex:
+        rec_bytes = F.DETS_DTYPE.itemsize * 4
+        ring = torch.zeros((3, rec_bytes), dtype=torch.uint8, device="cuda")
+        ex.set_ring(ring.data_ptr(), 3)
+        order = [frames, frames[::-1].copy(), frames, frames[::-1].copy(), frames]
+        for k, fr in enumerate(order):
+            ex.forward_host(fr)
+            dets = ex.read_dets()
+            slot = np.frombuffer(ring[k % 3].cpu().numpy().tobytes(), F.DETS_DTYPE, 4)
+            assert slot.tobytes() == dets.tobytes(), "forward %d" % k
+        ex.set_ring(None, 0)                          # detached: the ring stays as it is
+        before = ring.cpu().numpy().copy()
+        ex.forward_host(frames[::-1].copy())
+        ex.read_dets()
+        assert (ring.cpu().numpy() == before).all()
+
+
 def test_branch_parallel_executor(F, net, frames, oracle_runs, monkeypatch):
     """the first detection head as a parallel graph branch (own stream, disjoint arena) and with FFGPU_BRANCH=0"""
     for flags, br in ((0, "1"), (4, "1"), (0, "0")):
