@@ -211,6 +211,7 @@ def main():
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the multi-GPU step (RCCL gather of the records on a side stream) even with one rank")
+    ap.add_argument("--no-split", action="store_true", help="one chain of 64 frames instead of two parallel half-batch chains")
     ap.add_argument("--gather-every", type=int, default=32,
                     help="multi-GPU: steps whose records travel in one RCCL gather (fewer, larger collectives)")
     args = ap.parse_args()
@@ -263,7 +264,10 @@ def main():
     # last, partial group is flushed inside the timed region.
     gather_mode = world > 1 or args.force_gather
     host_dets = not gather_mode
-    exs = [net.executor(B, capi.FFGPU.HOST_DETS if host_dets else 0)]
+    # FFGPU_SPLIT2: the two halves of the batch run as two parallel branches of the graph (fills the latency gaps of
+    # the many small launches; measured 3.6 % with two separate executors: tools/split_batch.py)
+    split = 0 if args.no_split else capi.FFGPU.SPLIT2
+    exs = [net.executor(B, (capi.FFGPU.HOST_DETS if host_dets else 0) | split)]
     ex = exs[0]
 
     # synthetic frames (seeded per rank); frame 0 of rank 0 is the letterboxed test.bmp so boxes can be checked
@@ -376,7 +380,7 @@ def main():
             "config": {"workload": "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[3]/[4])",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "launches_per_step": ex.kernel_count, "arena_MB": round(ex.arena_bytes / 2**20, 1),
-                       "executors": 1, "gather": ("RCCL gather of %d steps' records + D2H on a side stream, overlapped with the next steps" % M) if gather_mode else "records written to pinned host memory by the NMS kernel",
+                       "executors": 1, "split": "two half-batch chains as parallel graph branches" if split else "none", "gather": ("RCCL gather of %d steps' records + D2H on a side stream, overlapped with the next steps" % M) if gather_mode else "records written to pinned host memory by the NMS kernel",
                        "weights": "data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL, untimed)",
                        "boxes_match_reference_golden_frame0": ok},
         }

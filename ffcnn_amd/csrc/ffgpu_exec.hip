@@ -58,6 +58,8 @@ extern "C" int ffgpu_set_device(int ordinal)
 }
 
 // --------------------------------------------------------------------------
+#define FFGPU_INTERNAL_CHILD 0x40000000   /* executor flag used only inside this file: a half of a split executor */
+
 enum StepKind { S_CONV, S_POOL, S_UPSAMPLE, S_ADD, S_COPY, S_YOLO, S_NMS, S_CLEAR, S_TOCNHW, S_IRB };
 
 struct Step {
@@ -113,6 +115,9 @@ struct ffgpu_exec {
     ffgpu_frame_dets *d_dets = nullptr;
     ffgpu_frame_dets *h_dets = nullptr, *h_dets_dev = nullptr;   // FFGPU_HOST_DETS: pinned mirror and its device address
     ffgpu_frame_dets *ring = nullptr; int ring_slots = 0; int *d_ringctr = nullptr;   // ffgpu_exec_set_ring
+    int ring_stride = 0;               // records per ring slot (the parent's batch for the halves of a split executor)
+    ffgpu_exec *child[2] = { nullptr, nullptr };   // FFGPU_SPLIT2: two half-batch executors that run as parallel graph branches
+    bool is_child = false;             // records / mirror / ring belong to the parent
     int    s1 = 1, s2 = 1;
     hipStream_t own_stream = nullptr, last_stream = nullptr;
     hipStream_t side_stream = nullptr;              // second graph branch
@@ -255,7 +260,9 @@ static int plan(ffgpu_exec *ex)
     ex->side_lo = ex->side_hi = -1;
     // MEASURED (r01): 1.5 % slower than the single chain while the head kernels were slow, 2 % FASTER once they were
     // latency-sized (0.766 vs 0.782 ms per 64-frame batch) -> on by default; FFGPU_BRANCH=0 turns it off.
-    const bool branch = !getenv("FFGPU_BRANCH") || atoi(getenv("FFGPU_BRANCH"));
+    // (not inside the halves of a split executor: a fork nested in a forked stream crashes graph capture on ROCm 7.0,
+    //  and the second half-batch chain already fills the gaps the head branch was meant to fill)
+    const bool branch = (!getenv("FFGPU_BRANCH") || atoi(getenv("FFGPU_BRANCH"))) && !ex->is_child;
     if (fuse && branch) {
         for (int y = 0; y + 1 < L; y++) {
             if (ll[y].type != LAYER_TYPE_YOLO || ll[y + 1].type != LAYER_TYPE_ROUTE || ll[y + 1].depend_num != 1) continue;
@@ -506,7 +513,7 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
     case S_YOLO:
         return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand, s);
     case S_NMS:
-        return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->d_dets, ex->h_dets_dev, ex->ring, ex->ring_slots, ex->d_ringctr, ex->N, 0.5f, 1, ex->s1, ex->s2, s);
+        return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->d_dets, ex->h_dets_dev, ex->ring, ex->ring_slots, ex->ring_stride ? ex->ring_stride : ex->N, ex->d_ringctr, ex->N, 0.5f, 1, ex->s1, ex->s2, s);
     }
     return -1;
 }
@@ -538,10 +545,29 @@ static int issue_all(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
     return 0;
 }
 
+// FFGPU_SPLIT2: the two halves of the batch are two independent chains of the same 40-odd launches; issued on two
+// streams they become two parallel branches of one graph.  Most of the launches are bound by a wave's serial chain and
+// a few microseconds of launch / first-load latency, not by a pipe: the second chain fills those gaps.
+static int issue_all(ffgpu_exec *ex, const float *d_frames, hipStream_t s);
+static int issue_split(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
+{
+    const size_t half = (size_t)ex->child[0]->N * ex->in_c * ex->in_h * ex->in_w;
+    FFGPU_CHECK(hipEventRecord(ex->ev_fork, s));
+    FFGPU_CHECK(hipStreamWaitEvent(ex->side_stream, ex->ev_fork, 0));
+    if (issue_all(ex->child[0], d_frames, s) != 0) return -1;
+    if (issue_all(ex->child[1], d_frames + half, ex->side_stream) != 0) return -1;
+    FFGPU_CHECK(hipEventRecord(ex->ev_join, ex->side_stream));
+    FFGPU_CHECK(hipStreamWaitEvent(s, ex->ev_join, 0));
+    return 0;
+}
+
 static int forward_on(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
 {
     ex->last_stream = s;
-    if (ex->flags & FFGPU_NO_GRAPH) return issue_all(ex, d_frames, s);
+    if (ex->child[0]) {
+        for (int c = 0; c < 2; c++) { ex->child[c]->s1 = ex->s1; ex->child[c]->s2 = ex->s2; ex->child[c]->last_stream = s; }
+    }
+    if (ex->flags & FFGPU_NO_GRAPH) return ex->child[0] ? issue_split(ex, d_frames, s) : issue_all(ex, d_frames, s);
     ffgpu_exec::GraphKey key{ d_frames, ex->s1, ex->s2 };
     auto it = ex->graphs.find(key);
     if (it == ex->graphs.end()) {
@@ -555,7 +581,7 @@ static int forward_on(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
         // null stream, which cannot be captured); replay goes to `s`
         hipStream_t cs = ex->own_stream;
         FFGPU_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        const int rc = issue_all(ex, d_frames, cs);
+        const int rc = ex->child[0] ? issue_split(ex, d_frames, cs) : issue_all(ex, d_frames, cs);
         hipError_t e = hipStreamEndCapture(cs, &graph);
         if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return -1; }
         if (e != hipSuccess) { ffgpu_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return -1; }
@@ -589,8 +615,11 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
     if (env && atoi(env)) flags |= FFGPU_NO_GRAPH;
     env = getenv("FFGPU_NO_FUSE");
     if (env && atoi(env)) flags |= FFGPU_NO_FUSE;
+    const bool split = (flags & FFGPU_SPLIT2) && batch >= 2 && batch % 2 == 0 && !(flags & FFGPU_KEEP_ALL);
+    const bool as_child = (flags & FFGPU_INTERNAL_CHILD) != 0;
+    flags &= ~(FFGPU_SPLIT2 | FFGPU_INTERNAL_CHILD);
     ffgpu_exec *ex = new ffgpu_exec();
-    ex->net = net; ex->dev = dev; ex->N = batch; ex->flags = flags;
+    ex->net = net; ex->dev = dev; ex->N = batch; ex->flags = flags; ex->is_child = as_child;
     ex->in_c = net->layer_list[0].c; ex->in_h = net->layer_list[0].h; ex->in_w = net->layer_list[0].w;
     bool ok = hipStreamCreateWithFlags(&ex->own_stream, hipStreamNonBlocking) == hipSuccess
            && hipStreamCreateWithFlags(&ex->side_stream, hipStreamNonBlocking) == hipSuccess
@@ -608,8 +637,22 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
         if (ok) memset(ex->h_dets, 0, sizeof(ffgpu_frame_dets) * (size_t)batch);
     }
     if (!ok) { ffgpu_set_error("executor buffers: %s", hipGetErrorString(hipGetLastError())); ffgpu_exec_destroy(ex); return nullptr; }
-    if (plan(ex) != 0 || repack(ex, ex->own_stream) != 0 || hipStreamSynchronize(ex->own_stream) != hipSuccess) { ffgpu_exec_destroy(ex); return nullptr; }
     ex->last_stream = ex->own_stream;
+    if (split) {
+        // the parent owns the records (and their mirror / ring); each half plans its own arena and writes its slice
+        for (int c = 0; c < 2; c++) {
+            ffgpu_exec *ch = ffgpu_exec_create(net, batch / 2, (flags & ~FFGPU_HOST_DETS) | FFGPU_INTERNAL_CHILD);
+            if (!ch) { ffgpu_exec_destroy(ex); return nullptr; }
+            (void)hipFree(ch->d_dets);
+            ch->d_dets = ex->d_dets + (size_t)c * (batch / 2);
+            ch->h_dets_dev = ex->h_dets_dev ? ex->h_dets_dev + (size_t)c * (batch / 2) : nullptr;
+            ex->child[c] = ch;
+            ex->kernel_count += ch->kernel_count;
+            ex->arena_floats += ch->arena_floats;
+        }
+        return ex;
+    }
+    if (plan(ex) != 0 || repack(ex, ex->own_stream) != 0 || hipStreamSynchronize(ex->own_stream) != hipSuccess) { ffgpu_exec_destroy(ex); return nullptr; }
     dev->execs.push_back(ex);
     return ex;
 }
@@ -618,6 +661,8 @@ extern "C" void ffgpu_exec_destroy(ffgpu_exec *ex)
 {
     if (!ex) return;
     if (ex->last_stream) (void)hipStreamSynchronize(ex->last_stream);
+    for (int c = 0; c < 2; c++) if (ex->child[c]) { ffgpu_exec_destroy(ex->child[c]); ex->child[c] = nullptr; }
+    if (ex->is_child) ex->d_dets = nullptr;                      // a slice of the parent's records
     if (ex->dev) ex->dev->execs.erase(std::remove(ex->dev->execs.begin(), ex->dev->execs.end(), ex), ex->dev->execs.end());
     for (auto &g : ex->graphs) (void)hipGraphExecDestroy(g.second);
     for (const Step &st : ex->steps) if (st.kind == S_TOCNHW) (void)hipFree(st.out);
@@ -698,6 +743,11 @@ extern "C" int ffgpu_exec_set_ring(ffgpu_exec *ex, void *dev_ring, int slots)
     ex->graphs.clear();
     ex->ring = (ffgpu_frame_dets *)dev_ring; ex->ring_slots = dev_ring ? slots : 0;
     FFGPU_CHECK(hipMemset(ex->d_ringctr, 0, sizeof(int)));
+    for (int c = 0; c < 2; c++) if (ex->child[c]) {             // each half writes its slice of every slot
+        ffgpu_exec *ch = ex->child[c];
+        ch->ring = dev_ring ? ex->ring + (size_t)c * ch->N : nullptr; ch->ring_slots = ex->ring_slots; ch->ring_stride = ex->N;
+        FFGPU_CHECK(hipMemset(ch->d_ringctr, 0, sizeof(int)));
+    }
     return 0;
 }
 
@@ -721,6 +771,7 @@ extern "C" int ffgpu_exec_read_dets(ffgpu_exec *ex, ffgpu_frame_dets *host_out, 
 extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float *host_out, size_t cap_floats)
 {
     if (!ex || !host_out || frame < 0 || frame >= ex->N) { ffgpu_set_error("read_layer: bad arguments"); return -1; }
+    if (ex->child[0]) return ffgpu_exec_read_layer(ex->child[frame >= ex->child[0]->N], layer, frame % ex->child[0]->N, host_out, cap_floats);
     FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
     if (layer == -2) {                                            // candidates in reference emission order
         int cnt = 0;
@@ -755,6 +806,7 @@ extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float
 extern "C" int ffgpu_exec_profile(ffgpu_exec *ex, const float *d_frames, float us_by_kind[LAYER_TYPE_TOTOAL])
 {
     if (!ex || !d_frames || !us_by_kind) { ffgpu_set_error("profile: NULL argument"); return -1; }
+    if (ex->child[0]) { ffgpu_set_error("profile: not available on a split executor"); return -1; }
     hipStream_t s = ex->own_stream;
     std::vector<hipEvent_t> ev(ex->steps.size() + 1);
     for (auto &e : ev) FFGPU_CHECK(hipEventCreate(&e));
@@ -780,6 +832,7 @@ extern "C" int ffgpu_exec_profile(ffgpu_exec *ex, const float *d_frames, float u
 extern "C" int ffgpu_exec_profile_steps(ffgpu_exec *ex, const float *d_frames, int *layer_of, float *us, int cap)
 {
     if (!ex || !d_frames || !layer_of || !us) { ffgpu_set_error("profile_steps: NULL argument"); return -1; }
+    if (ex->child[0]) { ffgpu_set_error("profile_steps: not available on a split executor"); return -1; }
     hipStream_t s = ex->own_stream;
     const int n = (int)std::min<size_t>(ex->steps.size(), (size_t)cap);
     std::vector<hipEvent_t> ev(ex->steps.size() + 1);

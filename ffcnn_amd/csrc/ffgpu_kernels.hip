@@ -304,7 +304,7 @@ __global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *
 // the start of the forward) goes to slot (*ring_ctr - 1) % ring_slots -- the multi-GPU job gathers whole groups of slots
 __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_key, const int *ncand,
                                              ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, ffgpu_frame_dets *ring, int ring_slots,
-                                             const int *ring_ctr, float thresh, int use_min, int s1, int s2)
+                                             int ring_stride, const int *ring_ctr, float thresh, int use_min, int s1, int s2)
 {
 #pragma clang fp contract(off)
     __shared__ float s_score[FFGPU_MAX_CAND];
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_k
     }
     __syncthreads();
     ffgpu_frame_dets *outs[3] = { out, dets_host ? dets_host + n : nullptr, nullptr };
-    if (ring) outs[2] = ring + (size_t)((unsigned)(*ring_ctr - 1) % (unsigned)ring_slots) * gridDim.x + n;
+    if (ring) outs[2] = ring + (size_t)((unsigned)(*ring_ctr - 1) % (unsigned)ring_slots) * ring_stride + n;
     // slots at or beyond both the previous and the new count are zero already in the record and its host mirror (both
     // start zeroed and are only ever written here): the mirror, which sits across PCIe, is touched only where it
     // changes.  A ring slot last held some older forward's record, so it is written in full.
@@ -493,10 +493,10 @@ int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand,
 }
 
 int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, const int *ncand, ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
-                     ffgpu_frame_dets *ring, int ring_slots, const int *ring_ctr, int N,
+                     ffgpu_frame_dets *ring, int ring_slots, int ring_stride, const int *ring_ctr, int N,
                      float thresh, int use_min, int s1, int s2, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_nms, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, dets, dets_host, ring, ring_slots, ring_ctr, thresh, use_min, s1, s2);
+    hipLaunchKernelGGL(k_nms, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, dets, dets_host, ring, ring_slots, ring_stride, ring_ctr, thresh, use_min, s1, s2);
     LAUNCH_OK("nms");
     return 0;
 }

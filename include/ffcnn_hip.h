@@ -50,6 +50,9 @@ typedef struct ffgpu_exec ffgpu_exec;     /* a planned executor: one NET x one b
 #define FFGPU_NO_FUSE    8    /* one kernel per reference layer (no cross-layer fusion)      */
 #define FFGPU_HOST_DETS  16   /* the NMS kernel also writes the records to a pinned host     */
                               /* mirror (ffgpu_exec_dets_host): no D2H copy after a forward   */
+#define FFGPU_SPLIT2     32   /* even batch: the two halves run as two parallel branches of   */
+                              /* one graph (same results; fills the latency gaps of the       */
+                              /* small-plane launches); not with FFGPU_KEEP_ALL               */
 
 /* ---- process / device --------------------------------------------------- */
 int         ffgpu_device_count(void);

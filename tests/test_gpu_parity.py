@@ -184,6 +184,28 @@ def test_host_mirror_of_records(F, net, frames, oracle_runs):
             ex.dets_host()
 
 
+@pytest.mark.parametrize("flags", [32, 32 | 4, 32 | 16, 32 | 16 | 8])
+def test_split_executor(F, net, frames, oracle_runs, flags):
+    """FFGPU_SPLIT2: two half-batch chains as parallel graph branches give the same records (also mirrored / ring)"""
+    import torch
+    with net.executor(4, flags) as ex:
+        rec_bytes = F.DETS_DTYPE.itemsize * 4
+        ring = torch.zeros((2, rec_bytes), dtype=torch.uint8, device="cuda")
+        ex.set_ring(ring.data_ptr(), 2)
+        for rep, fr in enumerate((frames, frames[::-1].copy(), frames)):
+            ex.forward_host(fr)
+            dets = ex.read_dets()
+            want = oracle_runs if rep != 1 else oracle_runs[::-1]
+            for f in range(4):
+                assert dets[f]["ncand"] == len(want[f]["cand"]) and dets[f]["overflow"] == 0
+                boxes_match(ex.read_candidates(f), want[f]["cand"], "cand frame %d" % f)
+                boxes_match(ex.boxes(f, dets), want[f]["boxes"], "boxes frame %d" % f)
+            slot = np.frombuffer(ring[rep % 2].cpu().numpy().tobytes(), F.DETS_DTYPE, 4)
+            assert slot.tobytes() == dets.tobytes()
+            if flags & 16:
+                assert ex.dets_host().tobytes() == dets.tobytes()
+
+
 def test_record_ring(F, net, frames, oracle_runs):
     """ffgpu_exec_set_ring: forward k also lands in slot k % slots of a caller-owned device ring"""
     import torch
