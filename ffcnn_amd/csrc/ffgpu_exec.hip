@@ -116,7 +116,10 @@ struct ffgpu_exec {
     ffgpu_frame_dets *h_dets = nullptr, *h_dets_dev = nullptr;   // FFGPU_HOST_DETS: pinned mirror and its device address
     ffgpu_frame_dets *ring = nullptr; int ring_slots = 0; int *d_ringctr = nullptr;   // ffgpu_exec_set_ring
     int ring_stride = 0;               // records per ring slot (the parent's batch for the halves of a split executor)
-    ffgpu_exec *child[2] = { nullptr, nullptr };   // FFGPU_SPLIT2: two half-batch executors that run as parallel graph branches
+    static constexpr int MAXPART = 8;
+    ffgpu_exec *child[MAXPART] = {};   // FFGPU_SPLIT2: part-batch executors that run as parallel graph branches
+    int nchild = 0;
+    hipStream_t part_stream[MAXPART] = {}; hipEvent_t part_ev[MAXPART] = {};   // branch c >= 1 runs on part_stream[c]
     bool is_child = false;             // records / mirror / ring belong to the parent
     int    s1 = 1, s2 = 1;
     hipStream_t own_stream = nullptr, last_stream = nullptr;
@@ -551,13 +554,15 @@ static int issue_all(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
 static int issue_all(ffgpu_exec *ex, const float *d_frames, hipStream_t s);
 static int issue_split(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
 {
-    const size_t half = (size_t)ex->child[0]->N * ex->in_c * ex->in_h * ex->in_w;
+    const size_t part = (size_t)ex->child[0]->N * ex->in_c * ex->in_h * ex->in_w;
     FFGPU_CHECK(hipEventRecord(ex->ev_fork, s));
-    FFGPU_CHECK(hipStreamWaitEvent(ex->side_stream, ex->ev_fork, 0));
-    if (issue_all(ex->child[0], d_frames, s) != 0) return -1;
-    if (issue_all(ex->child[1], d_frames + half, ex->side_stream) != 0) return -1;
-    FFGPU_CHECK(hipEventRecord(ex->ev_join, ex->side_stream));
-    FFGPU_CHECK(hipStreamWaitEvent(s, ex->ev_join, 0));
+    for (int c = 1; c < ex->nchild; c++) FFGPU_CHECK(hipStreamWaitEvent(ex->part_stream[c], ex->ev_fork, 0));
+    for (int c = 0; c < ex->nchild; c++)
+        if (issue_all(ex->child[c], d_frames + c * part, c ? ex->part_stream[c] : s) != 0) return -1;
+    for (int c = 1; c < ex->nchild; c++) {
+        FFGPU_CHECK(hipEventRecord(ex->part_ev[c], ex->part_stream[c]));
+        FFGPU_CHECK(hipStreamWaitEvent(s, ex->part_ev[c], 0));
+    }
     return 0;
 }
 
@@ -565,7 +570,7 @@ static int forward_on(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
 {
     ex->last_stream = s;
     if (ex->child[0]) {
-        for (int c = 0; c < 2; c++) { ex->child[c]->s1 = ex->s1; ex->child[c]->s2 = ex->s2; ex->child[c]->last_stream = s; }
+        for (int c = 0; c < ex->nchild; c++) { ex->child[c]->s1 = ex->s1; ex->child[c]->s2 = ex->s2; ex->child[c]->last_stream = s; }
     }
     if (ex->flags & FFGPU_NO_GRAPH) return ex->child[0] ? issue_split(ex, d_frames, s) : issue_all(ex, d_frames, s);
     ffgpu_exec::GraphKey key{ d_frames, ex->s1, ex->s2 };
@@ -639,16 +644,22 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
     if (!ok) { ffgpu_set_error("executor buffers: %s", hipGetErrorString(hipGetLastError())); ffgpu_exec_destroy(ex); return nullptr; }
     ex->last_stream = ex->own_stream;
     if (split) {
-        // the parent owns the records (and their mirror / ring); each half plans its own arena and writes its slice
-        for (int c = 0; c < 2; c++) {
-            ffgpu_exec *ch = ffgpu_exec_create(net, batch / 2, (flags & ~FFGPU_HOST_DETS) | FFGPU_INTERNAL_CHILD);
+        // the parent owns the records (and their mirror / ring); each part plans its own arena and writes its slice
+        int K = 2;
+        const char *ek = getenv("FFGPU_SPLIT_PARTS");            // tuning: 2 (default), 4 or 8 parallel chains
+        if (ek && (atoi(ek) == 4 || atoi(ek) == 8) && batch % atoi(ek) == 0) K = atoi(ek);
+        for (int c = 0; c < K; c++) {
+            ffgpu_exec *ch = ffgpu_exec_create(net, batch / K, (flags & ~FFGPU_HOST_DETS) | FFGPU_INTERNAL_CHILD);
             if (!ch) { ffgpu_exec_destroy(ex); return nullptr; }
             (void)hipFree(ch->d_dets);
-            ch->d_dets = ex->d_dets + (size_t)c * (batch / 2);
-            ch->h_dets_dev = ex->h_dets_dev ? ex->h_dets_dev + (size_t)c * (batch / 2) : nullptr;
-            ex->child[c] = ch;
+            ch->d_dets = ex->d_dets + (size_t)c * (batch / K);
+            ch->h_dets_dev = ex->h_dets_dev ? ex->h_dets_dev + (size_t)c * (batch / K) : nullptr;
+            ex->child[c] = ch; ex->nchild = c + 1;
             ex->kernel_count += ch->kernel_count;
             ex->arena_floats += ch->arena_floats;
+            if (c && (hipStreamCreateWithFlags(&ex->part_stream[c], hipStreamNonBlocking) != hipSuccess ||
+                      hipEventCreateWithFlags(&ex->part_ev[c], hipEventDisableTiming) != hipSuccess)) {
+                ffgpu_set_error("split executor: stream / event creation failed"); ffgpu_exec_destroy(ex); return nullptr; }
         }
         return ex;
     }
@@ -661,7 +672,11 @@ extern "C" void ffgpu_exec_destroy(ffgpu_exec *ex)
 {
     if (!ex) return;
     if (ex->last_stream) (void)hipStreamSynchronize(ex->last_stream);
-    for (int c = 0; c < 2; c++) if (ex->child[c]) { ffgpu_exec_destroy(ex->child[c]); ex->child[c] = nullptr; }
+    for (int c = 0; c < ffgpu_exec::MAXPART; c++) {
+        if (ex->child[c]) { ffgpu_exec_destroy(ex->child[c]); ex->child[c] = nullptr; }
+        if (ex->part_stream[c]) (void)hipStreamDestroy(ex->part_stream[c]);
+        if (ex->part_ev[c]) (void)hipEventDestroy(ex->part_ev[c]);
+    }
     if (ex->is_child) ex->d_dets = nullptr;                      // a slice of the parent's records
     if (ex->dev) ex->dev->execs.erase(std::remove(ex->dev->execs.begin(), ex->dev->execs.end(), ex), ex->dev->execs.end());
     for (auto &g : ex->graphs) (void)hipGraphExecDestroy(g.second);
@@ -743,7 +758,7 @@ extern "C" int ffgpu_exec_set_ring(ffgpu_exec *ex, void *dev_ring, int slots)
     ex->graphs.clear();
     ex->ring = (ffgpu_frame_dets *)dev_ring; ex->ring_slots = dev_ring ? slots : 0;
     FFGPU_CHECK(hipMemset(ex->d_ringctr, 0, sizeof(int)));
-    for (int c = 0; c < 2; c++) if (ex->child[c]) {             // each half writes its slice of every slot
+    for (int c = 0; c < ex->nchild; c++) {                      // each part writes its slice of every slot
         ffgpu_exec *ch = ex->child[c];
         ch->ring = dev_ring ? ex->ring + (size_t)c * ch->N : nullptr; ch->ring_slots = ex->ring_slots; ch->ring_stride = ex->N;
         FFGPU_CHECK(hipMemset(ch->d_ringctr, 0, sizeof(int)));
@@ -771,7 +786,7 @@ extern "C" int ffgpu_exec_read_dets(ffgpu_exec *ex, ffgpu_frame_dets *host_out, 
 extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float *host_out, size_t cap_floats)
 {
     if (!ex || !host_out || frame < 0 || frame >= ex->N) { ffgpu_set_error("read_layer: bad arguments"); return -1; }
-    if (ex->child[0]) return ffgpu_exec_read_layer(ex->child[frame >= ex->child[0]->N], layer, frame % ex->child[0]->N, host_out, cap_floats);
+    if (ex->child[0]) return ffgpu_exec_read_layer(ex->child[frame / ex->child[0]->N], layer, frame % ex->child[0]->N, host_out, cap_floats);
     FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
     if (layer == -2) {                                            // candidates in reference emission order
         int cnt = 0;
