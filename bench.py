@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--force-gather", action="store_true",
                     help="run the multi-GPU step (RCCL gather of the records on a side stream) even with one rank")
     ap.add_argument("--no-split", action="store_true", help="one chain of 64 frames instead of two parallel half-batch chains")
-    ap.add_argument("--gather-every", type=int, default=32,
+    ap.add_argument("--gather-every", type=int, default=64,
                     help="multi-GPU: steps whose records travel in one RCCL gather (fewer, larger collectives)")
     args = ap.parse_args()
 
@@ -256,11 +256,11 @@ def main():
     # (FFGPU_HOST_DETS), so the boxes are on the host when the step ends with no copy between two graph launches.
     # Several GPUs: the library's NMS kernel also writes each forward's records into a slot of a device ring
     # (ffgpu_exec_set_ring; nothing but graph launches sits on the compute stream); every --gather-every steps a side
-    # stream gathers the finished group over RCCL (one 6 MB message per rank instead of thirty-two 200 KB ones: xGMI
+    # stream gathers the finished group over RCCL (one 12 MB message per rank instead of sixty-four 200 KB ones: xGMI
     # collectives are latency-bound at this size) and moves the gathered block to rank 0's host while the next
     # forwards already run.  A cross-stream hand-over costs the compute stream ~0.4 ms on this stack (measured with one
-    # rank: 0.900 ms per step when every step ships, 0.789 / 0.785 / 0.780 for groups of 16 / 32 / 64, 0.766 without),
-    # which is why it is paid per group; the boxes of a step reach rank 0 at most one group (~25 ms) later, and the
+    # rank, split executor: 0.716 / 0.698 / 0.695 ms per step for groups of 32 / 64 / 128, 0.682 without),
+    # which is why it is paid per group; the boxes of a step reach rank 0 at most one group (~45 ms) later, and the
     # last, partial group is flushed inside the timed region.
     gather_mode = world > 1 or args.force_gather
     host_dets = not gather_mode
