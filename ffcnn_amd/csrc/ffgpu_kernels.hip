@@ -559,6 +559,55 @@ __global__ void __launch_bounds__(256) k_membench(mb4 *dst, const mb4 *src, long
     }
 }
 
+// ---------------------------------------------------------------------------
+// pipe probe (diagnostics): how the matrix cores and the vector ALU of a SIMD share time.  Every wave runs `iters` trips
+// of [NM independent v_mfma_f32_16x16x4_f32] + [NV independent v_fma_f32]; blocks * 4 waves are launched so the
+// caller controls waves per SIMD.  Result: microseconds per launch.
+template <int NM, int NV>
+__global__ void __launch_bounds__(256) k_pipe_probe(float *out, int iters)
+{
+    typedef float pv4 __attribute__((ext_vector_type(4)));
+    pv4 acc[16];
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc[i] = (pv4){ 0.f, 0.f, 0.f, 0.f }; v[i] = (float)threadIdx.x + i; }
+    const float a = 1.0f + threadIdx.x * 1e-6f, b = 0.999f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < NM; i++) acc[i & 15] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i & 15], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NV; i++) v[i & 15] = fmaf(v[i & 15], b, a);
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r += acc[i].x + acc[i].y + acc[i].z + acc[i].w + v[i];
+    if (r == 12345.678f) out[threadIdx.x] = r;                  // keep the work alive
+}
+
+extern "C" float ffgpu_pipe_probe(int n_mfma, int n_valu, int blocks, int iters, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    static float *d_out = nullptr;
+    if (!d_out && hipMalloc(&d_out, 256 * sizeof(float)) != hipSuccess) return -1.f;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
+    for (int rep = 0; rep < 3; rep++) {
+        if (rep == 1) (void)hipEventRecord(e0, s);
+        if (n_mfma == 16 && n_valu == 0)       hipLaunchKernelGGL((k_pipe_probe<16, 0>), dim3(blocks), dim3(256), 0, s, d_out, iters);
+        else if (n_mfma == 0 && n_valu == 64)  hipLaunchKernelGGL((k_pipe_probe<0, 64>), dim3(blocks), dim3(256), 0, s, d_out, iters);
+        else if (n_mfma == 16 && n_valu == 64) hipLaunchKernelGGL((k_pipe_probe<16, 64>), dim3(blocks), dim3(256), 0, s, d_out, iters);
+        else if (n_mfma == 16 && n_valu == 128) hipLaunchKernelGGL((k_pipe_probe<16, 128>), dim3(blocks), dim3(256), 0, s, d_out, iters);
+        else if (n_mfma == 0 && n_valu == 128) hipLaunchKernelGGL((k_pipe_probe<0, 128>), dim3(blocks), dim3(256), 0, s, d_out, iters);
+        else { ffgpu_set_error("pipe_probe: unsupported mix"); return -1.f; }
+    }
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms * 1000.f / 2;
+}
+
 extern "C" float ffgpu_membench(void *d_dst, const void *d_src, size_t bytes, int mode, int blocks, int iters, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;

@@ -173,6 +173,10 @@ float ffgpu_irb_dev(const float *d_in, const float *d_w1, const float *d_wd, con
  * 4: copy, 4 independent 16-byte loads in flight per lane.  Used by bench.py
  * to report the measured copy ceiling next to the 8 TB/s spec. */
 float ffgpu_membench(void *d_dst, const void *d_src, size_t bytes, int mode, int blocks, int iters, void *stream);
+/* Pipe probe: every wave of `blocks` x 4 runs `iters` trips of n_mfma independent v_mfma_f32_16x16x4_f32 plus n_valu
+ * independent v_fma_f32 (supported mixes: 16/0, 0/64, 16/64, 16/128, 0/128); returns microseconds per launch.  Shows
+ * whether matrix-core and vector-ALU work of one wave / of several waves of a SIMD overlap. */
+float ffgpu_pipe_probe(int n_mfma, int n_valu, int blocks, int iters, void *stream);
 
 #ifdef __cplusplus
 }
