@@ -314,19 +314,19 @@ def main():
         if not gather_mode:                                     # one in-order stream: no events, no copies
             ex.forward_dev(x.data_ptr(), stream.cuda_stream)
             return
-        g, slot = (i // M) % 2, i % M
+        g, slot = ffdist.ring_slot(i, M)
         with torch.cuda.stream(stream):
             if slot == 0:
                 stream.wait_event(ev_comm[g])                   # this group's previous gather has read it
             ex.forward_dev(x.data_ptr(), stream.cuda_stream)
             shipped["group"], shipped["slot"] = g, slot
-            if slot == M - 1:
+            if ffdist.group_due(i, M):
                 ship(g)
 
     def flush(n_done):                                          # a partial last group still has to travel
         if gather_mode and n_done % M != 0:
             with torch.cuda.stream(stream):
-                ship((n_done // M) % 2)
+                ship(ffdist.ring_slot(n_done, M)[0])
 
     def restart():                                              # forwards are counted from 0 again (slot 0 of group 0)
         if gather_mode:

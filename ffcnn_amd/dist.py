@@ -4,7 +4,9 @@ The forward path has no cross-frame state, so the batch i
 contiguous per-rank slices, every rank runs the whole net on its slice, and exactly two
 collectives exist:
   * once, at load: broadcast of the folded filter rows (NET.weight_buf layout) from rank 0;
-  * per step: gather of the fixed-size per-frame detection records (ffgpu_frame_dets) to rank 0.
+  * gather of the fixed-size per-frame detection records (ffgpu_frame_dets) to rank 0 -- in GROUPS of steps: forward k
+    writes its records into slot k % (2 M) of a ring (ffgpu_exec_set_ring), and every M steps the finished half of the
+    ring travels in one collective (ring_slot / group_due / unpack_group below).
 One process per GPU; `torch.distributed` with backend "nccl" (= RCCL over xGMI) on the GPUs and
 "gloo" in the CPU tests.  Nothing here touches a kernel: the functions move opaque byte tensors.
 """
@@ -45,3 +47,24 @@ def merge_records(per_rank_bytes, frames_per_rank, dets_dtype):
         a = np.frombuffer(bytes(buf), dets_dtype)
         parts.append(a[:n])
     return np.concatenate(parts) if parts else np.zeros(0, dets_dtype)
+
+
+# ---- record ring: which half / slot a step's records sit in, when a half is due, how rank 0 unpacks a gathered half
+def ring_slot(step, group_steps):
+    """(half of the ring, slot inside the half) that forward number `step` (0-based since the ring was set) writes."""
+    return (step // group_steps) % 2, step % group_steps
+
+
+def group_due(step, group_steps):
+    """True when forward number `step` completes a half of the ring (it is then gathered on the side stream)."""
+    return step % group_steps == group_steps - 1
+
+
+def unpack_group(gathered, n_steps, rec_bytes):
+    """gathered: per-rank byte buffers of one half of the ring (group_steps * rec_bytes each).
+    Returns [step][rank] -> bytes of that step's records, for the first n_steps slots (a flushed, partial half has
+    fewer valid slots than the half has room for)."""
+    out = []
+    for s in range(n_steps):
+        out.append([bytes(memoryview(g)[s * rec_bytes:(s + 1) * rec_bytes]) for g in gathered])
+    return out

@@ -85,3 +85,53 @@ def test_two_rank_broadcast_and_gather(total):
     assert all(r[0] and r[1] for r in res), res
     assert sorted(r[2] for r in res) == [0, total]
     assert DETS_DTYPE.itemsize == 16 + 24 * FFGPU.MAX_DET
+
+
+# ---- the record ring of the multi-GPU step: forwards write slots, halves travel in groups, the last half is flushed
+def _ring_worker(rank, world, port, steps, M, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rec_bytes = 48
+        ring = torch.zeros((2, M, rec_bytes), dtype=torch.uint8)                # what ffgpu_exec_set_ring hands the kernel
+        out = [torch.empty(M * rec_bytes, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+        seen = {}
+
+        def ship(g, n_valid, first_step):
+            got = ffdist.gather_records(dist, ring[g].view(-1), dst=0, out=out)
+            if rank == 0:
+                for s, per_rank in enumerate(ffdist.unpack_group([t.numpy() for t in got], n_valid, rec_bytes)):
+                    seen[first_step + s] = per_rank
+
+        for i in range(steps):
+            g, slot = ffdist.ring_slot(i, M)
+            ring[g, slot] = torch.full((rec_bytes,), (i * 7 + rank * 3) % 251, dtype=torch.uint8)   # "the NMS kernel"
+            if ffdist.group_due(i, M):
+                ship(g, M, i - M + 1)
+        if steps % M:
+            ship(ffdist.ring_slot(steps, M)[0], steps % M, steps - steps % M)                        # flush
+        ok = None
+        if rank == 0:
+            ok = sorted(seen) == list(range(steps)) and all(
+                seen[i][r] == bytes([(i * 7 + r * 3) % 251]) * rec_bytes for i in range(steps) for r in range(world))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps,M", [(10, 4), (8, 4), (3, 8), (17, 1)])
+def test_record_ring_groups_gloo(steps, M):
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, steps, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] is True
