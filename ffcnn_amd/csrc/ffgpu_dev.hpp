@@ -71,8 +71,8 @@ struct YoloHead {
     float thresh, scale_xy;
     int   key_base;        // emission-order key of this head's first candidate
 };
-int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, hipStream_t s);
-int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, const int *ncand, ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
+int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, int *ring_ctr, hipStream_t s);
+int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
                      ffgpu_frame_dets *ring, int ring_slots, int ring_stride, const int *ring_ctr, int N,
                      float thresh, int use_min, int s1, int s2, hipStream_t s);
 int ffgpu_launch_clear(int *ncand, int N, int *ring_ctr, hipStream_t s);

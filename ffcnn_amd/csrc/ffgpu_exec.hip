@@ -464,6 +464,12 @@ static int plan(ffgpu_exec *ex)
             }
         }
     }
+    // with a detection head in the net no clear launch is needed: k_nms zeroes the candidate counters it has consumed
+    // (they start zeroed) and the first head counts the forward for the record ring
+    if (nheads > 0 && fuse) {
+        S.erase(std::remove_if(S.begin(), S.end(), [](const Step &t) { return t.kind == S_CLEAR; }), S.end());
+        for (Step &t : S) if (t.kind == S_YOLO) { t.flag = 1; break; }
+    }
     { Step nm{}; nm.kind = S_NMS; nm.layer = -1; nm.ltype = LAYER_TYPE_YOLO; S.push_back(nm); }
     for (Step &st : S) st.lane = (ex->side_lo >= 0 && st.layer >= ex->side_lo && st.layer <= ex->side_hi) ? 1 : 0;
     ex->kernel_count = (int)S.size();
@@ -514,7 +520,8 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
     case S_IRB:
         return ffgpu_launch_irb(st.irb, s);
     case S_YOLO:
-        return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand, s);
+        return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand,
+                                 (st.flag && ex->ring) ? ex->d_ringctr : nullptr, s);
     case S_NMS:
         return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->d_dets, ex->h_dets_dev, ex->ring, ex->ring_slots, ex->ring_stride ? ex->ring_stride : ex->N, ex->d_ringctr, ex->N, 0.5f, 1, ex->s1, ex->s2, s);
     }
@@ -632,7 +639,7 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
            && hipEventCreateWithFlags(&ex->ev_join, hipEventDisableTiming) == hipSuccess
            && hipMalloc(&ex->d_cand, sizeof(BBOX) * FFGPU_MAX_CAND * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_cand_key, sizeof(int) * FFGPU_MAX_CAND * (size_t)batch) == hipSuccess
-           && hipMalloc(&ex->d_ncand, sizeof(int) * (size_t)batch) == hipSuccess
+           && hipMalloc(&ex->d_ncand, sizeof(int) * (size_t)batch) == hipSuccess && hipMemset(ex->d_ncand, 0, sizeof(int) * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_ringctr, sizeof(int)) == hipSuccess && hipMemset(ex->d_ringctr, 0, sizeof(int)) == hipSuccess
            && hipMemset(ex->d_dets, 0, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess;
@@ -790,7 +797,7 @@ extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float
     FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
     if (layer == -2) {                                            // candidates in reference emission order
         int cnt = 0;
-        FFGPU_CHECK(hipMemcpy(&cnt, ex->d_ncand + frame, sizeof(int), hipMemcpyDeviceToHost));
+        FFGPU_CHECK(hipMemcpy(&cnt, &ex->d_dets[frame].ncand, sizeof(int), hipMemcpyDeviceToHost));    // (k_nms has reset d_ncand)
         cnt = std::min(cnt, FFGPU_MAX_CAND);
         if ((size_t)cnt * 6 > cap_floats) { ffgpu_set_error("read_layer: buffer too small"); return -1; }
         std::vector<BBOX> b(cnt);

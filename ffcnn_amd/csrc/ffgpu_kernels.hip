@@ -232,9 +232,11 @@ __global__ void k_input_bgr(const unsigned char *bgr, float *out, int N, int w, 
 // lanes run along x so the 85 strided channel reads are coalesced.  exp() is
 // evaluated in double and narrowed exactly where the reference does, and FMA
 // contraction is off so the confidence/box arithmetic rounds like the C code.
-__global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand)
+// ring_ctr (one head of a forward only, may be NULL): this forward's number for the record ring -- counted here, consumed by k_nms
+__global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, int *ring_ctr)
 {
 #pragma clang fp contract(off)
+    if (ring_ctr && blockIdx.x == 0 && threadIdx.x == 0) *ring_ctr += 1;
     const int cells = hd.w * hd.h;
     const long total = (long)N * 3 * cells;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,7 +304,7 @@ __global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *
 // single-GPU consumer needs no device-to-host copy after the forward
 // ring (may be NULL): caller-owned device ring of ring_slots x N records; forward number *ring_ctr (counted by k_clear at
 // the start of the forward) goes to slot (*ring_ctr - 1) % ring_slots -- the multi-GPU job gathers whole groups of slots
-__global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_key, const int *ncand,
+__global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_key, int *ncand,
                                              ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, ffgpu_frame_dets *ring, int ring_slots,
                                              int ring_stride, const int *ring_ctr, float thresh, int use_min, int s1, int s2)
 {
@@ -392,13 +394,15 @@ __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_k
         if (i < nwrite) { outs[0]->box[i] = r; if (outs[1]) outs[1]->box[i] = r; }
         if (outs[2]) outs[2]->box[i] = r;
     }
-    if (tid == 0)
+    if (tid == 0) {
         for (int k = 0; k < 3; k++) if (outs[k]) {
             outs[k]->count = s_nkeep;
             outs[k]->ncand = total;
             outs[k]->overflow = (total > FFGPU_MAX_CAND) | s_clipped;
             outs[k]->reserved = 0;
         }
+        ncand[n] = 0;                                              // the next forward's heads start counting from zero (no clear launch)
+    }
 }
 
 // start of a forward: no candidates yet; one more forward for the record ring
@@ -484,15 +488,15 @@ int ffgpu_launch_input_bgr(const unsigned char *bgr, float *out, int N, int w, i
     return 0;
 }
 
-int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, hipStream_t s)
+int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, int *ring_ctr, hipStream_t s)
 {
     const long total = (long)N * 3 * hd.w * hd.h;
-    hipLaunchKernelGGL(k_yolo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hd, N, netw, neth, cand, cand_key, ncand);
+    hipLaunchKernelGGL(k_yolo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hd, N, netw, neth, cand, cand_key, ncand, ring_ctr);
     LAUNCH_OK("yolo");
     return 0;
 }
 
-int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, const int *ncand, ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
+int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
                      ffgpu_frame_dets *ring, int ring_slots, int ring_stride, const int *ring_ctr, int N,
                      float thresh, int use_min, int s1, int s2, hipStream_t s)
 {
