@@ -206,6 +206,27 @@ def test_split_executor(F, net, frames, oracle_runs, flags):
                 assert ex.dets_host().tobytes() == dets.tobytes()
 
 
+@pytest.mark.parametrize("flags", [0, 32, 32 | 16])
+def test_repeated_forwards_are_bit_identical(F, net, frames, flags):
+    """60 graph replays on the same frames: records identical every time (races between the parallel chains /
+    branches, the counter hand-over between k_nms and the next forward's heads, ring slots)"""
+    import torch
+    with net.executor(4, flags) as ex:
+        rec_bytes = F.DETS_DTYPE.itemsize * 4
+        ring = torch.zeros((5, rec_bytes), dtype=torch.uint8, device="cuda")
+        ex.set_ring(ring.data_ptr(), 5)
+        x = torch.from_numpy(frames).cuda()
+        first = None
+        for k in range(60):
+            ex.forward_dev(x.data_ptr())
+            if k % 7 == 0 or k == 59:
+                d = ex.read_dets().tobytes()
+                first = first or d
+                assert d == first, "replay %d differs" % k
+                assert ring[k % 5].cpu().numpy().tobytes() == first, "ring slot of replay %d" % k
+        assert sum(int(c) for c in np.frombuffer(first, F.DETS_DTYPE, 4)["count"]) > 0
+
+
 def test_record_ring(F, net, frames, oracle_runs):
     """ffgpu_exec_set_ring: forward k also lands in slot k % slots of a caller-owned device ring"""
     import torch
