@@ -379,6 +379,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[3]/[4])",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       # unfused activation traffic 60.11 MB per frame -> 3.85 GB per 64-frame batch ->
+                       # 0.48 ms at 8 TB/s -> 133 k frames/s per GPU if every layer ran at the HBM roofline UNFUSED
+                       "frac_of_unfused_hbm_ceiling": round(fps / world / (8.0e12 / 60.11e6), 4),
                        "launches_per_step": ex.kernel_count, "arena_MB": round(ex.arena_bytes / 2**20, 1),
                        "executors": 1, "split": "two half-batch chains as parallel graph branches" if split else "none", "gather": ("RCCL gather of %d steps' records + D2H on a side stream, overlapped with the next steps" % M) if gather_mode else "records written to pinned host memory by the NMS kernel",
                        "weights": "data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL, untimed)",
