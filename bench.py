@@ -211,7 +211,9 @@ def main():
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the multi-GPU step (RCCL gather of the records on a side stream) even with one rank")
-    ap.add_argument("--no-split", action="store_true", help="one chain of 64 frames instead of two parallel half-batch chains")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="executors (one stream each) that take the batches in turn: up to that many batches are in flight")
+    ap.add_argument("--split", action="store_true", help="FFGPU_SPLIT2 executors (two half-batch chains per batch)")
     ap.add_argument("--gather-every", type=int, default=64,
                     help="multi-GPU: steps whose records travel in one RCCL gather (fewer, larger collectives)")
     args = ap.parse_args()
@@ -264,10 +266,18 @@ def main():
     # last, partial group is flushed inside the timed region.
     gather_mode = world > 1 or args.force_gather
     host_dets = not gather_mode
-    # FFGPU_SPLIT2: the two halves of the batch run as two parallel branches of the graph (fills the latency gaps of
-    # the many small launches; measured 3.6 % with two separate executors: tools/split_batch.py)
-    split = 0 if args.no_split else capi.FFGPU.SPLIT2
-    exs = [net.executor(B, (capi.FFGPU.HOST_DETS if host_dets else 0) | split)]
+    # Batches are independent, so consecutive steps go to S executors on S streams in turn (each its own arena and graph,
+    # no events between them): while one batch is in its latency-bound tail (10x10 / 20x20 planes) the next one is in its
+    # throughput-bound head, and the two use the chip in a complementary way -- 0.71 ms per 64 frames with one chain,
+    # 0.66 with FFGPU_SPLIT2 (two half-batch chains in lockstep), 0.49 / 0.46 with two / three whole-batch chains
+    # (tools/split_batch.py).  The head branch inside a chain is off here: more chains do its job with fewer forks.
+    S = max(1, args.streams)
+    if gather_mode and 2 * max(1, args.gather_every) % S:
+        raise SystemExit("--gather-every * 2 must be a multiple of --streams")
+    os.environ.setdefault("FFGPU_BRANCH", "0" if S > 1 else "1")
+    flags = (capi.FFGPU.HOST_DETS if host_dets else 0) | (capi.FFGPU.SPLIT2 if args.split else 0)
+    exs = [net.executor(B, flags) for _ in range(S)]
+    streams = [stream] + [torch.cuda.Stream() for _ in range(S - 1)]
     ex = exs[0]
 
     # synthetic frames (seeded per rank); frame 0 of rank 0 is the letterboxed test.bmp so boxes can be checked
@@ -297,41 +307,45 @@ def main():
     glist = list(big.unbind(0)) if big is not None else None
     host = [torch.empty((world, M * dbytes), dtype=torch.uint8).pin_memory() for _ in range(2)] if (gather_mode and rank == 0) else None
     comm = torch.cuda.Stream() if gather_mode else None
-    ev_fwd = [torch.cuda.Event() for _ in range(2)]
     ev_comm = [torch.cuda.Event() for _ in range(2)]
     shipped = {"group": -1, "slot": 0}                          # where the newest step's records sit on rank 0's host
 
+    ev_fwd = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
+
     def ship(g):                                                # side stream: gather group g of the ring, D2H on rank 0
-        ev_fwd[g].record(stream)
+        for j in range(S):
+            ev_fwd[g][j].record(streams[j])
         with torch.cuda.stream(comm):
-            comm.wait_event(ev_fwd[g])
+            for j in range(S):
+                comm.wait_event(ev_fwd[g][j])                   # every chain has written its slots of the group
             ffdist.gather_records(dist, ring[g].view(-1), dst=0, out=glist)
             if rank == 0:
                 host[g].copy_(big, non_blocking=True)           # one D2H copy for the whole job's records of the group
             ev_comm[g].record(comm)
 
     def step(i):
-        if not gather_mode:                                     # one in-order stream: no events, no copies
-            ex.forward_dev(x.data_ptr(), stream.cuda_stream)
+        j = i % S                                               # executor / stream of this step
+        if not gather_mode:                                     # in-order streams: no events, no copies
+            exs[j].forward_dev(x.data_ptr(), streams[j].cuda_stream)
+            shipped["group"] = j
             return
         g, slot = ffdist.ring_slot(i, M)
-        with torch.cuda.stream(stream):
-            if slot == 0:
-                stream.wait_event(ev_comm[g])                   # this group's previous gather has read it
-            ex.forward_dev(x.data_ptr(), stream.cuda_stream)
-            shipped["group"], shipped["slot"] = g, slot
-            if ffdist.group_due(i, M):
-                ship(g)
+        if slot < S:
+            streams[j].wait_event(ev_comm[g])                   # this group's previous gather has read it
+        exs[j].forward_dev(x.data_ptr(), streams[j].cuda_stream)
+        shipped["group"], shipped["slot"] = g, slot
+        if ffdist.group_due(i, M):
+            ship(g)
 
     def flush(n_done):                                          # a partial last group still has to travel
         if gather_mode and n_done % M != 0:
-            with torch.cuda.stream(stream):
-                ship(ffdist.ring_slot(n_done, M)[0])
+            ship(ffdist.ring_slot(n_done, M)[0])
 
     def restart():                                              # forwards are counted from 0 again (slot 0 of group 0)
         if gather_mode:
             torch.cuda.synchronize()
-            ex.set_ring(ring.data_ptr(), 2 * M)
+            for j, e in enumerate(exs):                         # executor j's forward k is global step k * S + j
+                e.set_ring(ring.data_ptr() + j * dbytes, 2 * M // S, S * B)
 
     def fence():
         torch.cuda.synchronize()
@@ -364,7 +378,7 @@ def main():
         ok = None
         if check is not None:
             if host_dets:
-                rec = exs[0].dets_host()
+                rec = exs[shipped["group"]].dets_host()
             else:                                               # rank 0's block of the newest group, newest slot
                 blk = host[shipped["group"]][0].numpy()[shipped["slot"] * dbytes:(shipped["slot"] + 1) * dbytes]
                 rec = np.frombuffer(blk.tobytes(), capi.DETS_DTYPE, B)
@@ -383,7 +397,7 @@ def main():
                        # 0.48 ms at 8 TB/s -> 133 k frames/s per GPU if every layer ran at the HBM roofline UNFUSED
                        "frac_of_unfused_hbm_ceiling": round(fps / world / (8.0e12 / 60.11e6), 4),
                        "launches_per_step": ex.kernel_count, "arena_MB": round(ex.arena_bytes / 2**20, 1),
-                       "executors": 1, "split": "two half-batch chains as parallel graph branches" if split else "none", "gather": ("RCCL gather of %d steps' records + D2H on a side stream, overlapped with the next steps" % M) if gather_mode else "records written to pinned host memory by the NMS kernel",
+                       "executors": S, "pipelining": "%d executors on %d streams take the batches in turn%s" % (S, S, ", each split in two half-batch chains" if args.split else ""), "gather": ("RCCL gather of %d steps' records + D2H on a side stream, overlapped with the next steps" % M) if gather_mode else "records written to pinned host memory by the NMS kernel",
                        "weights": "data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL, untimed)",
                        "boxes_match_reference_golden_frame0": ok},
         }

@@ -62,7 +62,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_net_weights_dev", "ffgpu_net_weights_commit",
            "ffgpu_exec_create", "ffgpu_exec_destroy", "ffgpu_exec_batch", "ffgpu_exec_arena_bytes",
            "ffgpu_exec_kernel_count", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
-           "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_set_ring", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
+           "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_set_ring", "ffgpu_exec_set_ring_strided", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
            "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_irb_dev"]
 
 
@@ -120,6 +120,7 @@ def lib():
     L.ffgpu_exec_dets_dev.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
     L.ffgpu_exec_dets_host.restype = vp; L.ffgpu_exec_dets_host.argtypes = [vp]
     L.ffgpu_exec_set_ring.argtypes = [vp, vp, C.c_int]
+    L.ffgpu_exec_set_ring_strided.argtypes = [vp, vp, C.c_int, C.c_int]
     L.ffgpu_exec_read_dets.argtypes = [vp, vp, i]
     L.ffgpu_exec_read_layer.argtypes = [vp, i, i, f32p, sz]
     L.ffgpu_exec_profile.argtypes = [vp, vp, f32p]
@@ -329,9 +330,13 @@ class Executor:
         buf = (C.c_char * (DETS_DTYPE.itemsize * self.batch)).from_address(ptr)
         return np.frombuffer(buf, DETS_DTYPE, self.batch)
 
-    def set_ring(self, dev_ptr, slots):
-        """forward k also writes its records into slot k % slots of the device buffer at dev_ptr (None detaches)"""
-        _check(lib().ffgpu_exec_set_ring(self.h, dev_ptr, slots), "ffgpu_exec_set_ring")
+    def set_ring(self, dev_ptr, slots, slot_records=None):
+        """forward k also writes its records into slot k % slots of the device buffer at dev_ptr (None detaches);
+        slot_records: distance between slots in records (default: the batch)"""
+        if slot_records is None:
+            _check(lib().ffgpu_exec_set_ring(self.h, dev_ptr, slots), "ffgpu_exec_set_ring")
+        else:
+            _check(lib().ffgpu_exec_set_ring_strided(self.h, dev_ptr, slots, slot_records), "ffgpu_exec_set_ring_strided")
 
     def read_dets(self):
         out = np.zeros(self.batch, DETS_DTYPE)

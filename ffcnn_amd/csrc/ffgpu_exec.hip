@@ -757,20 +757,26 @@ extern "C" int ffgpu_exec_dets_dev(ffgpu_exec *ex, void **dev_ptr, size_t *bytes
     return 0;
 }
 
-extern "C" int ffgpu_exec_set_ring(ffgpu_exec *ex, void *dev_ring, int slots)
+extern "C" int ffgpu_exec_set_ring_strided(ffgpu_exec *ex, void *dev_ring, int slots, int slot_records)
 {
-    if (!ex || (dev_ring && slots < 1)) { ffgpu_set_error("set_ring: bad arguments"); return -1; }
+    if (!ex || (dev_ring && (slots < 1 || slot_records < ex->N))) { ffgpu_set_error("set_ring: bad arguments"); return -1; }
     FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
     for (auto &g : ex->graphs) (void)hipGraphExecDestroy(g.second);      // the ring pointer is a kernel argument of the graphs
     ex->graphs.clear();
-    ex->ring = (ffgpu_frame_dets *)dev_ring; ex->ring_slots = dev_ring ? slots : 0;
+    ex->ring = (ffgpu_frame_dets *)dev_ring; ex->ring_slots = dev_ring ? slots : 0; ex->ring_stride = slot_records;
     FFGPU_CHECK(hipMemset(ex->d_ringctr, 0, sizeof(int)));
     for (int c = 0; c < ex->nchild; c++) {                      // each part writes its slice of every slot
         ffgpu_exec *ch = ex->child[c];
-        ch->ring = dev_ring ? ex->ring + (size_t)c * ch->N : nullptr; ch->ring_slots = ex->ring_slots; ch->ring_stride = ex->N;
+        ch->ring = dev_ring ? ex->ring + (size_t)c * ch->N : nullptr; ch->ring_slots = ex->ring_slots; ch->ring_stride = slot_records;
         FFGPU_CHECK(hipMemset(ch->d_ringctr, 0, sizeof(int)));
     }
     return 0;
+}
+
+extern "C" int ffgpu_exec_set_ring(ffgpu_exec *ex, void *dev_ring, int slots)
+{
+    if (!ex) { ffgpu_set_error("set_ring: NULL executor"); return -1; }
+    return ffgpu_exec_set_ring_strided(ex, dev_ring, slots, ex->N);
 }
 
 extern "C" const ffgpu_frame_dets *ffgpu_exec_dets_host(ffgpu_exec *ex)

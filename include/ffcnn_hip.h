@@ -104,6 +104,10 @@ const ffgpu_frame_dets *ffgpu_exec_dets_host(ffgpu_exec *ex);
  * records), so groups of steps travel in one collective with no copy between graph launches.  Calling it again
  * (or with NULL) restarts the count / detaches.  Synchronises the executor's stream. */
 int ffgpu_exec_set_ring(ffgpu_exec *ex, void *dev_ring, int slots);
+/* The same with slot k at dev_ring + k * slot_records records (slot_records >= batch): E executors that take turns on E
+ * streams share one ring when executor e gets dev_ring + e * batch records, slots / E slots and slot_records = E * batch
+ * -- its forward k then lands in the ring's slot k * E + e, i.e. the global step number. */
+int ffgpu_exec_set_ring_strided(ffgpu_exec *ex, void *dev_ring, int slots, int slot_records);
 /* Synchronise the executor's last stream and copy the records to the host. */
 int ffgpu_exec_read_dets(ffgpu_exec *ex, ffgpu_frame_dets *host_out, int max_frames);
 

@@ -227,6 +227,25 @@ def test_repeated_forwards_are_bit_identical(F, net, frames, flags):
         assert sum(int(c) for c in np.frombuffer(first, F.DETS_DTYPE, 4)["count"]) > 0
 
 
+def test_strided_ring_shared_by_executors(F, net, frames):
+    """two executors taking turns share one ring: executor e writes slots e, e + 2, ... (ffgpu_exec_set_ring_strided)"""
+    import torch
+    rec = F.DETS_DTYPE.itemsize * 4
+    ring = torch.zeros((4, rec), dtype=torch.uint8, device="cuda")
+    rev = frames[::-1].copy()
+    with net.executor(4, 0) as e0, net.executor(4, 0) as e1:
+        e0.set_ring(ring.data_ptr(), 2, 2 * 4)
+        e1.set_ring(ring.data_ptr() + rec, 2, 2 * 4)
+        want = {}
+        for step in range(6):
+            ex, fr = (e0, frames) if step % 2 == 0 else (e1, rev)
+            ex.forward_host(fr)
+            want[step % 4] = ex.read_dets().tobytes()
+            got = ring.cpu().numpy()
+            for slot, b in want.items():
+                assert got[slot].tobytes() == b, "step %d slot %d" % (step, slot)
+
+
 def test_record_ring(F, net, frames, oracle_runs):
     """ffgpu_exec_set_ring: forward k also lands in slot k % slots of a caller-owned device ring"""
     import torch
