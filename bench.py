@@ -349,6 +349,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # every executor captures its graph on its first forward: do that once per executor before anything is counted
+    # (with --warmup smaller than --streams some captures would otherwise land inside the timed region)
+    for j in range(S):
+        exs[j].forward_dev(x.data_ptr(), streams[j].cuda_stream)
+    torch.cuda.synchronize()
+    if gather_mode:                                             # ... and RCCL sets its communicator up on the first collective
+        with torch.cuda.stream(comm):
+            ffdist.gather_records(dist, ring[0].view(-1), dst=0, out=glist)
+        torch.cuda.synchronize()
     # warm-up and timed steps are numbered from 0 each, so both start on a fresh group and end with a flush
     restart()
     for i in range(args.warmup):
