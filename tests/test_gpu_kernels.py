@@ -215,6 +215,19 @@ def test_irb_fused_block(env, shape):
     check(out.cpu().numpy(), ref, "irb %s" % (shape,))
 
 
+@pytest.mark.parametrize("tile", [(0, 0), (5, 6), (4, 8), (2, 10), (8, 4)])
+@pytest.mark.parametrize("shape", [(8, 32, 8, 1, 2, 80, 80, True), (8, 48, 16, 1, 3, 40, 40, False), (16, 96, 16, 1, 2, 40, 40, True),
+                                   (8, 32, 8, 1, 2, 13, 11, True), (5, 20, 7, 1, 1, 23, 30, True)])
+def test_irb_wave_two_strips(env, shape, tile, monkeypatch):
+    """two output strips per wave (k_irbw2): forced on small test planes, several tile shapes incl. ragged edges"""
+    monkeypatch.setenv("FFGPU_IRBW2_MIN_TILES", "1")
+    monkeypatch.setenv("FFGPU_IRBW_G", "1")
+    if tile[0]:
+        monkeypatch.setenv("FFGPU_IRBW2_TWQ", str(tile[0]))
+        monkeypatch.setenv("FFGPU_IRBW2_TH", str(tile[1]))
+    test_irb_fused_block(env, shape)
+
+
 @pytest.mark.parametrize("G", [1, 2, 3, 5, 8])
 @pytest.mark.parametrize("shape", [(24, 136, 24, 1, 3, 20, 20, True), (48, 224, 48, 1, 2, 10, 10, True), (8, 48, 16, 1, 2, 40, 40, False),
                                    (4, 24, 8, 2, 2, 48, 32, True)])
