@@ -489,6 +489,12 @@ static int repack(ffgpu_exec *ex, hipStream_t s)
 // -------------------------------------------------------------------------- running
 static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hipStream_t s)
 {
+    // tuning only (tools/ablate_layers.py): FFGPU_DBG_SKIP="lo:hi" drops the launches of layers lo..hi -- wrong results,
+    // but the change in frames/s is what that stretch of the net costs with several batches in flight
+    if (const char *sk = getenv("FFGPU_DBG_SKIP")) {
+        int lo = -1, hi = -1;
+        if (sscanf(sk, "%d:%d", &lo, &hi) == 2 && st.layer >= lo && st.layer <= hi && st.kind != S_NMS) return 0;
+    }
     switch (st.kind) {
     case S_CLEAR:
         return ffgpu_launch_clear(ex->d_ncand, ex->N, ex->ring ? ex->d_ringctr : nullptr, s);
