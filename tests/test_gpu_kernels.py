@@ -151,6 +151,16 @@ def test_dw_lds(env, orc, shape):
         check(outs[0].reshape(C, N, OH, OW)[:, n], o, "dw_lds %s frame %d vs oracle" % (shape, n))
 
 
+@pytest.mark.parametrize("pair", [1, 0])
+@pytest.mark.parametrize("shape", [(120, 3, 20, 20, 5, 1, 2, 0), (96, 5, 10, 10, 5, 1, 2, 0), (6, 70, 20, 20, 5, 1, 0, 0), (4, 2, 13, 6, 5, 1, 1, 0),
+                                   (2, 1, 7, 38, 5, 1, 2, 0), (8, 64, 40, 40, 5, 1, 2, 0), (10, 3, 22, 18, 5, 1, 2, 0)])
+def test_dw5_channel_pairs(env, orc, shape, pair, monkeypatch):
+    """depthwise 5x5 on small planes: the channel-pair kernel (k_dw_pair: frames split over several workgroups, ragged
+    bands / quads, W % 4 != 0) and, forced, the k_dw_lds path it replaces there -- against generic and the oracle"""
+    monkeypatch.setenv("FFGPU_NO_DW_PAIR", "0" if pair else "1")
+    test_dw_lds(env, orc, shape)
+
+
 @pytest.mark.parametrize("shape", [(256, 512, 2, 20, 20, 2), (128, 255, 1, 20, 20, 0), (64, 130, 3, 10, 10, 2), (100, 200, 1, 12, 12, 1)])
 def test_pw_gemm(env, orc, shape):
     capi, torch = env
