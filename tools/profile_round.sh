@@ -15,5 +15,7 @@ timeout 200 python tools/layer_profile.py 64 2>&1 | grep -v amdgpu.ids > gpurun_
 timeout 600 python tools/tune_irbw.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_irbw_sweep.txt
 FFGPU_NO_IRBW=1 timeout 500 tools/irb_trace.sh > gpurun_out/${TAG}_irb_timeline_workgroup_kernel.txt 2>&1
 timeout 500 tools/irb_trace.sh > gpurun_out/${TAG}_irb_timeline.txt 2>&1
-rm -rf gpurun_out/prof_${TAG} gpurun_out/prof_${TAG}_fwd
+timeout 400 bash tools/issue_budget.sh gpurun_out/${TAG}_issue_budget.txt > /dev/null 2>&1
+timeout 400 python tools/ablate_layers.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_ablation_4streams.txt
+rm -rf gpurun_out/prof_${TAG} gpurun_out/prof_${TAG}_fwd gpurun_out/pmc_issue
 tail -1 gpurun_out/${TAG}_bench.json | cut -c1-400
