@@ -250,6 +250,17 @@ def test_irb_fused_block(env, shape):
     check(out.cpu().numpy(), ref, "irb %s" % (shape,))
 
 
+@pytest.mark.parametrize("band", [0, 1, 3, 5, 16])
+@pytest.mark.parametrize("shape", [(8, 8, 4, 1, 2, 37, 160, False), (4, 8, 4, 1, 3, 21, 48, True), (8, 8, 8, 1, 1, 16, 256, True),
+                                   (4, 8, 8, 1, 2, 9, 4, False), (4, 8, 4, 1, 1, 1, 8, True), (8, 8, 4, 1, 2, 2, 12, False)])
+def test_irb_thin_bands(env, shape, band, monkeypatch):
+    """the 8-channel streaming block (k_irb_thin): every channel-count instantiation, rows split into bands of any length
+    (ragged last band, bands longer than the plane, single-row planes), 1 to 64 lanes per row"""
+    if band:
+        monkeypatch.setenv("FFGPU_THIN_BAND", str(band))
+    test_irb_fused_block(env, shape)
+
+
 @pytest.mark.parametrize("tile", [(0, 0), (5, 6), (4, 8), (2, 10), (8, 4)])
 @pytest.mark.parametrize("shape", [(8, 32, 8, 1, 2, 80, 80, True), (8, 48, 16, 1, 3, 40, 40, False), (16, 96, 16, 1, 2, 40, 40, True),
                                    (8, 32, 8, 1, 2, 13, 11, True), (5, 20, 7, 1, 1, 23, 30, True)])
