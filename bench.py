@@ -272,6 +272,8 @@ def main():
         raise SystemExit("--gather-every * 2 must be a multiple of --streams")
     os.environ.setdefault("FFGPU_BRANCH", "0" if S > 1 else "1")
     flags = (capi.FFGPU.HOST_DETS if host_dets else 0) | (capi.FFGPU.SPLIT2 if args.split else 0)
+    if S >= 3:
+        flags |= capi.FFGPU.CONCURRENT      # plan for throughput: several chains fill the device together
     exs = [net.executor(B, flags) for _ in range(S)]
     streams = [stream] + [torch.cuda.Stream() for _ in range(S - 1)]
     ex = exs[0]

@@ -17,7 +17,7 @@ f32p = C.POINTER(C.c_float)
 class FFGPU:
     MAX_DET = 128
     MAX_CAND = 1024
-    KEEP_ALL, COMPAT_V6, NO_GRAPH, NO_FUSE, HOST_DETS, SPLIT2 = 1, 2, 4, 8, 16, 32
+    KEEP_ALL, COMPAT_V6, NO_GRAPH, NO_FUSE, HOST_DETS, SPLIT2, CONCURRENT = 1, 2, 4, 8, 16, 32, 64
     K_AUTO, K_GENERIC, K_DW_STREAM, K_DW_LDS, K_PW_MFMA, K_PW_GEMM, K_PW_VALU, K_DENSE_SMALL = range(8)
 
 

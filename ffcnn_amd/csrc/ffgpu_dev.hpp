@@ -43,6 +43,7 @@ struct IrbDesc {
     int N, H, W, OH, OW, ic, ec, oc, stride;
     int act1, actd, act2, res_act;
     const float *pk;          // packed constants (ffgpu_irb_pack_floats floats, filled by ffgpu_irb_pack)
+    int flags;                // FFGPU_CONCURRENT: tile splits chosen for several chains in flight
 };
 bool   ffgpu_irb_supported(const IrbDesc &d);
 bool   ffgpu_irb_is_thin(const IrbDesc &d);      // 8 expanded channels: streaming VALU kernel instead of the MFMA/LDS one

@@ -201,7 +201,7 @@ static int plan(ffgpu_exec *ex)
             if (canon[p0] != p0 || canon[p0 + 1] != p0 + 1) continue;
             IrbDesc d{};
             d.N = N; d.H = a.h; d.W = a.w; d.OH = ll[p0 + 3].h; d.OW = ll[p0 + 3].w;
-            d.ic = a.c; d.ec = a.fn; d.oc = c.fn; d.stride = b.stride;
+            d.ic = a.c; d.ec = a.fn; d.oc = c.fn; d.stride = b.stride; d.flags = ex->flags & FFGPU_CONCURRENT;
             d.act1 = a.activation; d.actd = b.activation; d.act2 = c.activation;
             d.res_act = fused_into[p0 + 2] >= 0 ? ll[fused_into[p0 + 2]].activation : 0;
             static const int min_ec = getenv("FFGPU_IRB_MIN_EC") ? atoi(getenv("FFGPU_IRB_MIN_EC")) : 24;
@@ -349,7 +349,7 @@ static int plan(ffgpu_exec *ex)
                 d.w1 = ex->dev->d_weights + (la.filter - net->weight_buf);
                 d.wd = ex->dev->d_weights + (lb.filter - net->weight_buf);
                 d.w2 = ex->dev->d_weights + (lc.filter - net->weight_buf);
-                d.N = N; d.H = la.h; d.W = la.w; d.OH = b.h; d.OW = b.w;
+                d.N = N; d.H = la.h; d.W = la.w; d.OH = b.h; d.OW = b.w; d.flags = ex->flags & FFGPU_CONCURRENT;
                 d.ic = la.c; d.ec = la.fn; d.oc = lc.fn; d.stride = lb.stride;
                 d.act1 = la.activation; d.actd = lb.activation; d.act2 = lc.activation;
                 if (fused_into[i] >= 0) {

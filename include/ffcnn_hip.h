@@ -54,6 +54,11 @@ typedef struct ffgpu_exec ffgpu_exec;     /* a planned executor: one NET x one b
                               /* one graph (same results; fills the latency gaps of the       */
                               /* small-plane launches); not with FFGPU_KEEP_ALL               */
 
+#define FFGPU_CONCURRENT 64   /* several executors of this device run at the same time (one   */
+                              /* stream each): plan for throughput -- the small planes' tiles  */
+                              /* are split over fewer waves (less redundant work per wave; a   */
+                              /* lone chain is ~4 % slower, four in flight ~3.5 % faster)      */
+
 /* ---- process / device --------------------------------------------------- */
 int         ffgpu_device_count(void);
 int         ffgpu_set_device(int ordinal);            /* hipSetDevice for this thread        */

@@ -329,6 +329,24 @@ def test_forward_dev_torch_stream(F, net, frames, oracle_runs):
             boxes_match(ex.boxes(f, dets), oracle_runs[f]["boxes"], "frame %d" % f)
 
 
+@pytest.mark.parametrize("flags", [0, 64, 64 | 16])
+def test_batch64_plans(F, net, frames, oracle_runs, flags):
+    """batch 64 (the bench's batch: tile splits, band lengths and kernel choices that only big batches take), planned for one
+    chain in flight (0) and for several (FFGPU_CONCURRENT): every frame's records against the oracle's"""
+    big = np.ascontiguousarray(np.tile(frames, (16, 1, 1, 1)))
+    with net.executor(64, flags) as ex:
+        for rep in range(2):
+            ex.forward_host(big)
+            dets = ex.read_dets()
+            for f in range(64):
+                want = oracle_runs[f % 4]
+                assert dets[f]["ncand"] == len(want["cand"]) and dets[f]["overflow"] == 0
+                boxes_match(ex.read_candidates(f), want["cand"], "cand frame %d" % f)
+                boxes_match(ex.boxes(f, dets), want["boxes"], "boxes frame %d" % f)
+            if flags & 16:
+                assert ex.dets_host().tobytes() == dets.tobytes()
+
+
 def test_batch_sizes_and_arena(F, net, frames, oracle_runs):
     sizes = {}
     for b in (1, 2, 3):
