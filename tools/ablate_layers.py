@@ -18,7 +18,7 @@ for name, rng in SEG:
         os.environ["FFGPU_DBG_SKIP"] = "%d:%d" % rng
     else:
         os.environ.pop("FFGPU_DBG_SKIP", None)
-    exs = [net.executor(64, capi.FFGPU.HOST_DETS) for _ in range(4)]
+    exs = [net.executor(64, capi.FFGPU.HOST_DETS | capi.FFGPU.CONCURRENT) for _ in range(4)]
     sts = [torch.cuda.Stream() for _ in range(4)]
     def run(k):
         torch.cuda.synchronize()
