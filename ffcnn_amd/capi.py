@@ -63,7 +63,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_create", "ffgpu_exec_destroy", "ffgpu_exec_batch", "ffgpu_exec_arena_bytes",
            "ffgpu_exec_kernel_count", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
            "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_set_ring", "ffgpu_exec_set_ring_strided", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
-           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_irb_dev"]
+           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_pipe_probe2", "ffgpu_irb_dev"]
 
 
 def library_path():
@@ -136,6 +136,8 @@ def lib():
     L.ffgpu_membench.argtypes = [vp, vp, sz, i, i, i, vp]
     L.ffgpu_pipe_probe.restype = C.c_float
     L.ffgpu_pipe_probe.argtypes = [i, i, i, i, vp]
+    L.ffgpu_pipe_probe2.restype = C.c_float
+    L.ffgpu_pipe_probe2.argtypes = [i, i, i, i, vp]
     _lib = L
     return L
 

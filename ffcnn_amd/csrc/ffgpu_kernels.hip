@@ -588,6 +588,71 @@ __global__ void __launch_bounds__(256) k_pipe_probe(float *out, int iters)
     if (r == 12345.678f) out[threadIdx.x] = r;                  // keep the work alive
 }
 
+// ---- does vector-ALU work hide in the shadow of an MFMA?  Hand-placed instruction streams (inline asm, nothing for the
+// compiler to repack or reorder): MODE 0: 16 x MFMA; 1: 16 x (MFMA, NS plain v_fma_f32); 2: 16 x (MFMA, NS/2 v_pk_fma_f32);
+// 3: 16 x NS v_fma_f32 alone; 4: 16 x NS/2 v_pk_fma_f32 alone.  All operands independent of each other.
+template <int MODE, int NS>
+__global__ void __launch_bounds__(256) k_pipe_probe2(float *out, int iters)
+{
+    typedef float pv4 __attribute__((ext_vector_type(4)));
+    typedef float pv2 __attribute__((ext_vector_type(2)));
+    pv4 acc[16];
+    float v[8];
+    pv2 w[4];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = (pv4){ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (float)threadIdx.x + i;
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = (pv2){ (float)threadIdx.x + i, 1.f };
+    const float a = 1.0f + threadIdx.x * 1e-6f, b = 0.999f;
+    const pv2 b2 = { b, b }, a2 = { a, a };
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (MODE <= 2) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+            if (MODE == 1 || MODE == 3) {
+#pragma unroll
+                for (int j = 0; j < NS; j++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j & 7]) : "v"(b), "v"(a));
+            }
+            if (MODE == 2 || MODE == 4) {
+#pragma unroll
+                for (int j = 0; j < NS / 2; j++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(w[j & 3]) : "v"(b2), "v"(a2));
+            }
+        }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r += v[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) r += w[i].x + w[i].y;
+    if (r == 12345.678f) out[threadIdx.x] = r;
+}
+
+extern "C" float ffgpu_pipe_probe2(int mode, int ns, int blocks, int iters, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    static float *d_out = nullptr;
+    if (!d_out && hipMalloc(&d_out, 256 * sizeof(float)) != hipSuccess) return -1.f;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
+    for (int rep = 0; rep < 3; rep++) {
+        if (rep == 1) (void)hipEventRecord(e0, s);
+#define PP2(M, N) if (mode == M && ns == N) hipLaunchKernelGGL((k_pipe_probe2<M, N>), dim3(blocks), dim3(256), 0, s, d_out, iters); else
+        PP2(0, 0) PP2(1, 2) PP2(1, 4) PP2(1, 6) PP2(1, 8) PP2(2, 2) PP2(2, 4) PP2(2, 6) PP2(2, 8) PP2(3, 4) PP2(3, 8) PP2(4, 4) PP2(4, 8)
+        { ffgpu_set_error("pipe_probe2: unsupported mix"); return -1.f; }
+#undef PP2
+    }
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms * 1000.f / 2;
+}
+
 extern "C" float ffgpu_pipe_probe(int n_mfma, int n_valu, int blocks, int iters, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;

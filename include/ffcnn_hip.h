@@ -186,6 +186,9 @@ float ffgpu_membench(void *d_dst, const void *d_src, size_t bytes, int mode, int
  * independent v_fma_f32 (supported mixes: 16/0, 0/64, 16/64, 16/128, 0/128); returns microseconds per launch.  Shows
  * whether matrix-core and vector-ALU work of one wave / of several waves of a SIMD overlap. */
 float ffgpu_pipe_probe(int n_mfma, int n_valu, int blocks, int iters, void *stream);
+/* the same question with hand-placed instruction streams: mode 0 = 16 MFMAs per trip; 1 = each followed by `ns` plain
+ * v_fma_f32; 2 = by ns/2 v_pk_fma_f32; 3 / 4 = the vector instructions alone.  Microseconds per launch. */
+float ffgpu_pipe_probe2(int mode, int ns, int blocks, int iters, void *stream);
 
 #ifdef __cplusplus
 }
