@@ -50,6 +50,8 @@ bool   ffgpu_irb_is_thin(const IrbDesc &d);      // 8 expanded channels: streami
 size_t ffgpu_irb_pack_floats(const IrbDesc &d);
 int    ffgpu_irb_pack(const IrbDesc &d, float *pk, hipStream_t s);
 int    ffgpu_launch_irb(const IrbDesc &d, hipStream_t s);
+bool   ffgpu_front_ok(const ConvDesc &c, const IrbDesc &d);      // first layer (3x3 s2, 3 -> 8) + thin block as one streaming kernel
+int    ffgpu_launch_front(const ConvDesc &c, const IrbDesc &d, hipStream_t s);
 
 size_t ffgpu_pw_pack_floats(const ConvDesc &d);
 int    ffgpu_pw_pack(const ConvDesc &d, float *pk, hipStream_t s);

@@ -60,7 +60,7 @@ extern "C" int ffgpu_set_device(int ordinal)
 // --------------------------------------------------------------------------
 #define FFGPU_INTERNAL_CHILD 0x40000000   /* executor flag used only inside this file: a half of a split executor */
 
-enum StepKind { S_CONV, S_POOL, S_UPSAMPLE, S_ADD, S_COPY, S_YOLO, S_NMS, S_CLEAR, S_TOCNHW, S_IRB };
+enum StepKind { S_CONV, S_POOL, S_UPSAMPLE, S_ADD, S_COPY, S_YOLO, S_NMS, S_CLEAR, S_TOCNHW, S_IRB, S_FRONT };
 
 struct Step {
     StepKind kind;
@@ -434,6 +434,20 @@ static int plan(ffgpu_exec *ex)
         default: break;                                             // dropout
         }
     }
+    // first layer + the thin block behind it -> one streaming kernel (ffgpu_front.inc): the 8-channel tensor between them
+    // is never written (its arena space stays reserved; read_layer refuses it like the inside of a fused block)
+    if (fuse) {
+        for (size_t k = 0; k + 1 < S.size(); k++) {
+            Step &c0 = S[k];
+            const Step &b0 = S[k + 1];
+            if (c0.kind != S_CONV || b0.kind != S_IRB || c0.layer < 0 || nuses[c0.layer] != 1) continue;
+            if (!ffgpu_front_ok(c0.conv, b0.irb)) continue;
+            c0.kind = S_FRONT; c0.irb = b0.irb;
+            ex->readable[c0.layer] = 0;
+            S.erase(S.begin() + k + 1);
+            break;
+        }
+    }
     {   // constants of the fused blocks, packed once into their LDS image
         size_t tot = 0;
         for (Step &st : S) {
@@ -531,6 +545,10 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
         return 0; }
     case S_IRB:
         return ffgpu_launch_irb(st.irb, s);
+    case S_FRONT: {
+        ConvDesc d = st.conv;
+        if (st.in_is_input) d.in = d_frames;
+        return ffgpu_launch_front(d, st.irb, s); }
     case S_YOLO:
         return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand,
                                  (st.flag && ex->ring) ? ex->d_ringctr : nullptr, s);

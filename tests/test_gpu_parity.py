@@ -329,6 +329,23 @@ def test_forward_dev_torch_stream(F, net, frames, oracle_runs):
             boxes_match(ex.boxes(f, dets), oracle_runs[f]["boxes"], "frame %d" % f)
 
 
+def test_front_kernel_layers(F, net, frames, oracle_runs, monkeypatch):
+    """first layer + first thin block as one kernel (k_front; forced on a small batch): its output (layer 3) and everything
+    behind it against the oracle, frame by frame; the tensor it no longer writes (layer 0) must refuse to be read"""
+    monkeypatch.setenv("FFGPU_FRONT_MIN_PX", "1")
+    for band in ("", "1", "3", "16"):
+        if band:
+            monkeypatch.setenv("FFGPU_FRONT_BAND", band)
+        with net.executor(4, F.FFGPU.KEEP_ALL) as ex:
+            ex.forward_host(frames)
+            with pytest.raises(RuntimeError, match="not materialised"):
+                ex.read_layer(0, 0)
+            for i in (3, 8, 11, 21, 37, 57, 80, 108, 120, 129):
+                for f in range(4):
+                    close(ex.read_layer(i, f), oracle_runs[f]["acts"][i], "front band %s: frame %d layer %d" % (band, f, i))
+            assert ex.kernel_count <= 59
+
+
 @pytest.mark.parametrize("flags", [0, 64, 64 | 16])
 def test_batch64_plans(F, net, frames, oracle_runs, flags):
     """batch 64 (the bench's batch: tile splits, band lengths and kernel choices that only big batches take), planned for one
