@@ -213,6 +213,7 @@ def main():
                     help="run the multi-GPU step (RCCL gather of the records on a side stream) even with one rank")
     ap.add_argument("--streams", type=int, default=4,
                     help="executors (one stream each) that take the batches in turn: up to that many batches are in flight")
+    ap.add_argument("--input-sets", type=int, default=8, help="distinct synthetic batches resident in HBM, used in turn (8 x 78.6 MB does not fit the 256 MB Infinity Cache: every step reads its frames from HBM)")
     ap.add_argument("--split", action="store_true", help="FFGPU_SPLIT2 executors (two half-batch chains per batch)")
     ap.add_argument("--gather-every", type=int, default=64,
                     help="multi-GPU: steps whose records travel in one RCCL gather (fewer, larger collectives)")
@@ -292,6 +293,14 @@ def main():
             check = json.load(open(os.path.join(ROOT, "tests", "golden", "boxes.json")))["net_320x320_v0"]["boxes"]
         except Exception as e:
             print("bench: golden check unavailable: %r" % (e,), file=sys.stderr)
+    # the steps take K distinct batches in turn (frame 0 is the test image in each of them, the rest differs): one batch used
+    # over and over would sit in the 256 MB Infinity Cache and the first layer would never read HBM
+    K_in = max(1, args.input_sets)
+    xs = [x]
+    for k in range(1, K_in):
+        xk = torch.rand((B, 3, 320, 320), device="cuda", generator=g)
+        xk[0] = x[0]
+        xs.append(xk)
     for e in exs:
         e.set_scale(640, 320)   # every frame is treated as a 640-wide source letterboxed to 320 (test.bmp's ratio)
 
@@ -301,43 +310,51 @@ def main():
     # ring of two groups of M slots: the library's NMS kernel writes forward k's records into slot k % 2M itself
     # (ffgpu_exec_set_ring), so nothing but graph launches sits on the compute stream
     ring = torch.empty((2, M, dbytes), dtype=torch.uint8, device="cuda") if gather_mode else None
-    big = torch.empty((world, M * dbytes), dtype=torch.uint8, device="cuda") if (gather_mode and rank == 0) else None
+    # what travels is the COMPACT form of a step's records (ffgpu_pack_records on the side stream: 25 KB instead of 198 KB
+    # per step at batch 64 -- the fixed-size records are almost all unused box slots), room for 16 boxes per frame on average
+    CAP = 16 * B
+    pbytes = capi.packed_records_bytes(B, CAP)
+    cring = torch.empty((2, M, pbytes), dtype=torch.uint8, device="cuda") if gather_mode else None
+    big = torch.empty((world, M * pbytes), dtype=torch.uint8, device="cuda") if (gather_mode and rank == 0) else None
     glist = list(big.unbind(0)) if big is not None else None
-    host = [torch.empty((world, M * dbytes), dtype=torch.uint8).pin_memory() for _ in range(2)] if (gather_mode and rank == 0) else None
+    host = [torch.empty((world, M * pbytes), dtype=torch.uint8).pin_memory() for _ in range(2)] if (gather_mode and rank == 0) else None
     comm = torch.cuda.Stream() if gather_mode else None
     ev_comm = [torch.cuda.Event() for _ in range(2)]
     shipped = {"group": -1, "slot": 0}                          # where the newest step's records sit on rank 0's host
 
     ev_fwd = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
 
-    def ship(g):                                                # side stream: gather group g of the ring, D2H on rank 0
+    def ship(g, nslots=None):                                   # side stream: gather group g of the ring, D2H on rank 0
+        ns = M if nslots is None else nslots                   # a flushed, partial group moves only the slots that were written
+        nb = ns * pbytes
         for j in range(S):
             ev_fwd[g][j].record(streams[j])
         with torch.cuda.stream(comm):
             for j in range(S):
                 comm.wait_event(ev_fwd[g][j])                   # every chain has written its slots of the group
-            ffdist.gather_records(dist, ring[g].view(-1), dst=0, out=glist)
+            capi.pack_records_dev(ring[g].data_ptr(), ns, B, B, CAP, cring[g].data_ptr(), comm.cuda_stream)
+            ffdist.gather_records(dist, cring[g].view(-1)[:nb], dst=0, out=[t[:nb] for t in glist] if glist is not None else None)
             if rank == 0:
-                host[g].copy_(big, non_blocking=True)           # one D2H copy for the whole job's records of the group
+                host[g][:, :nb].copy_(big[:, :nb], non_blocking=True)   # one D2H copy for the whole job's records of the group
             ev_comm[g].record(comm)
 
     def step(i):
         j = i % S                                               # executor / stream of this step
         if not gather_mode:                                     # in-order streams: no events, no copies
-            exs[j].forward_dev(x.data_ptr(), streams[j].cuda_stream)
+            exs[j].forward_dev(xs[i % K_in].data_ptr(), streams[j].cuda_stream)
             shipped["group"] = j
             return
         g, slot = ffdist.ring_slot(i, M)
         if slot < S:
             streams[j].wait_event(ev_comm[g])                   # this group's previous gather has read it
-        exs[j].forward_dev(x.data_ptr(), streams[j].cuda_stream)
+        exs[j].forward_dev(xs[i % K_in].data_ptr(), streams[j].cuda_stream)
         shipped["group"], shipped["slot"] = g, slot
         if ffdist.group_due(i, M):
             ship(g)
 
     def flush(n_done):                                          # a partial last group still has to travel
         if gather_mode and n_done % M != 0:
-            ship(ffdist.ring_slot(n_done, M)[0])
+            ship(ffdist.ring_slot(n_done, M)[0], n_done % M)
 
     def restart():                                              # forwards are counted from 0 again (slot 0 of group 0)
         if gather_mode:
@@ -358,7 +375,7 @@ def main():
     torch.cuda.synchronize()
     if gather_mode:                                             # ... and RCCL sets its communicator up on the first collective
         with torch.cuda.stream(comm):
-            ffdist.gather_records(dist, ring[0].view(-1), dst=0, out=glist)
+            ffdist.gather_records(dist, cring[0].view(-1), dst=0, out=glist)
         torch.cuda.synchronize()
     # warm-up and timed steps are numbered from 0 each, so both start on a fresh group and end with a flush
     restart()
@@ -387,8 +404,8 @@ def main():
             if host_dets:
                 rec = exs[shipped["group"]].dets_host()
             else:                                               # rank 0's block of the newest group, newest slot
-                blk = host[shipped["group"]][0].numpy()[shipped["slot"] * dbytes:(shipped["slot"] + 1) * dbytes]
-                rec = np.frombuffer(blk.tobytes(), capi.DETS_DTYPE, B)
+                blk = host[shipped["group"]][0].numpy()[shipped["slot"] * pbytes:(shipped["slot"] + 1) * pbytes]
+                rec = ffdist.unpack_records(blk, capi.DETS_DTYPE)
             got = rec[0]["box"][: rec[0]["count"]]
             ok = bool(len(got) == len(check) and all(
                 int(a["type"]) == int(b["type"]) and abs(float(a["score"]) - float(b["score"])) < 1e-4 and
@@ -400,11 +417,12 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[3]/[4])",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "input_sets": K_in,
                        # unfused activation traffic 60.11 MB per frame -> 3.85 GB per 64-frame batch ->
                        # 0.48 ms at 8 TB/s -> 133 k frames/s per GPU if every layer ran at the HBM roofline UNFUSED
                        "frac_of_unfused_hbm_ceiling": round(fps / world / (8.0e12 / 60.11e6), 4),
                        "launches_per_step": ex.kernel_count, "arena_MB": round(ex.arena_bytes / 2**20, 1),
-                       "executors": S, "pipelining": "%d executors on %d streams take the batches in turn%s" % (S, S, ", each split in two half-batch chains" if args.split else ""), "gather": ("RCCL gather of %d steps' records + D2H on a side stream, overlapped with the next steps" % M) if gather_mode else "records written to pinned host memory by the NMS kernel",
+                       "executors": S, "pipelining": "%d executors on %d streams take the batches in turn%s" % (S, S, ", each split in two half-batch chains" if args.split else ""), "gather": ("RCCL gather of %d steps' records (packed: %d bytes per step and rank) + D2H on a side stream, overlapped with the next steps" % (M, pbytes)) if gather_mode else "records written to pinned host memory by the NMS kernel",
                        "weights": "data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL, untimed)",
                        "boxes_match_reference_golden_frame0": ok},
         }

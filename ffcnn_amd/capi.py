@@ -63,7 +63,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_create", "ffgpu_exec_destroy", "ffgpu_exec_batch", "ffgpu_exec_arena_bytes",
            "ffgpu_exec_kernel_count", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
            "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_set_ring", "ffgpu_exec_set_ring_strided", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
-           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_pipe_probe2", "ffgpu_irb_dev"]
+           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_pipe_probe2", "ffgpu_irb_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records"]
 
 
 def library_path():
@@ -136,6 +136,10 @@ def lib():
     L.ffgpu_membench.argtypes = [vp, vp, sz, i, i, i, vp]
     L.ffgpu_pipe_probe.restype = C.c_float
     L.ffgpu_pipe_probe.argtypes = [i, i, i, i, vp]
+    L.ffgpu_packed_records_bytes.restype = C.c_size_t
+    L.ffgpu_packed_records_bytes.argtypes = [i, i]
+    L.ffgpu_pack_records.restype = i
+    L.ffgpu_pack_records.argtypes = [vp, i, C.c_long, i, i, vp, vp]
     L.ffgpu_pipe_probe2.restype = C.c_float
     L.ffgpu_pipe_probe2.argtypes = [i, i, i, i, vp]
     _lib = L
@@ -386,6 +390,15 @@ def groupconv_time_dev(d_in, d_filt, d_out, batch, iw, ih, ic, groups, pad, stri
     if us < 0:
         raise RuntimeError("ffgpu_groupconv_time_dev failed: %s" % last_error())
     return us
+
+
+def packed_records_bytes(batch, cap):
+    return int(lib().ffgpu_packed_records_bytes(batch, cap))
+
+
+def pack_records_dev(d_records, nslots, slot_stride_records, batch, cap, d_out, stream=None):
+    """pack nslots steps of `batch` fixed-size records (device) into compact blocks (device): what the multi-GPU gather moves"""
+    _check(lib().ffgpu_pack_records(d_records, nslots, slot_stride_records, batch, cap, d_out, stream), "ffgpu_pack_records")
 
 
 def kernel_name(batch, iw, ih, ic, groups, pad, stride, fs, fn, variant=0):

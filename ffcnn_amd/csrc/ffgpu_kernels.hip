@@ -588,6 +588,51 @@ __global__ void __launch_bounds__(256) k_pipe_probe(float *out, int iters)
     if (r == 12345.678f) out[threadIdx.x] = r;                  // keep the work alive
 }
 
+// ---- compact form of the detection records for the multi-GPU gather: a step's `batch` fixed-size records (3088 bytes
+// each, almost all of it unused box slots) become
+//     int total, over, batch, cap | { int count, ncand, overflow, first } x batch | BBOX box[cap]
+// with each frame's boxes packed behind each other (frame order; `first` = index of its first box).  A step whose frames
+// hold more than `cap` boxes together keeps the first cap of them and says so (`over`, and `overflow |= 2` on the frames
+// that lost boxes).  One workgroup per step; 25 KB instead of 198 KB per step at batch 64, cap 1024.
+__global__ void __launch_bounds__(256) k_pack_records(const ffgpu_frame_dets *recs, long slot_stride_recs, int batch, int cap, unsigned char *out, long out_stride)
+{
+    __shared__ int s_first[1025];
+    const ffgpu_frame_dets *r = recs + (long)blockIdx.x * slot_stride_recs;
+    unsigned char *o = out + (long)blockIdx.x * out_stride;
+    int *hdr = reinterpret_cast<int *>(o);
+    int *fr = hdr + 4;
+    BBOX *box = reinterpret_cast<BBOX *>(fr + 4 * batch);
+    if (threadIdx.x == 0) {                                       // batch <= 1024: a serial prefix sum is a microsecond
+        int t = 0;
+        for (int n = 0; n < batch; n++) { s_first[n] = t; t += r[n].count; }
+        s_first[batch] = t;
+        hdr[0] = min(t, cap); hdr[1] = t > cap; hdr[2] = batch; hdr[3] = cap;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < batch; n += blockDim.x) {
+        const int first = s_first[n], cnt = r[n].count, kept = max(0, min(cnt, cap - first));
+        fr[4 * n] = kept; fr[4 * n + 1] = r[n].ncand; fr[4 * n + 2] = r[n].overflow | (kept < cnt ? 2 : 0); fr[4 * n + 3] = min(first, cap);
+    }
+    // boxes: 6 floats each, copied as 32-bit words by the whole workgroup
+    for (int n = 0; n < batch; n++) {
+        const int first = s_first[n], kept = max(0, min(r[n].count, cap - first));
+        const float *src = reinterpret_cast<const float *>(r[n].box);
+        float *dst = reinterpret_cast<float *>(box + first);
+        for (int i = threadIdx.x; i < kept * 6; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+extern "C" size_t ffgpu_packed_records_bytes(int batch, int cap) { return ((size_t)16 + 16 * (size_t)batch + sizeof(BBOX) * (size_t)cap + 15) & ~(size_t)15; }
+
+extern "C" int ffgpu_pack_records(const void *d_records, int nslots, long slot_stride_records, int batch, int cap, void *d_out, void *stream)
+{
+    if (!d_records || !d_out || nslots < 1 || batch < 1 || batch > 1024 || cap < 1) { ffgpu_set_error("pack_records: bad arguments"); return -1; }
+    hipLaunchKernelGGL(k_pack_records, dim3(nslots), dim3(256), 0, (hipStream_t)stream, (const ffgpu_frame_dets *)d_records, slot_stride_records,
+                       batch, cap, (unsigned char *)d_out, (long)ffgpu_packed_records_bytes(batch, cap));
+    if (hipGetLastError() != hipSuccess) { ffgpu_set_error("pack_records: launch failed"); return -1; }
+    return 0;
+}
+
 // ---- does vector-ALU work hide in the shadow of an MFMA?  Hand-placed instruction streams (inline asm, nothing for the
 // compiler to repack or reorder): MODE 0: 16 x MFMA; 1: 16 x (MFMA, NS plain v_fma_f32); 2: 16 x (MFMA, NS/2 v_pk_fma_f32);
 // 3: 16 x NS v_fma_f32 alone; 4: 16 x NS/2 v_pk_fma_f32 alone.  All operands independent of each other.

@@ -186,6 +186,15 @@ float ffgpu_membench(void *d_dst, const void *d_src, size_t bytes, int mode, int
  * independent v_fma_f32 (supported mixes: 16/0, 0/64, 16/64, 16/128, 0/128); returns microseconds per launch.  Shows
  * whether matrix-core and vector-ALU work of one wave / of several waves of a SIMD overlap. */
 float ffgpu_pipe_probe(int n_mfma, int n_valu, int blocks, int iters, void *stream);
+/* ---- compact records for the multi-GPU gather ("fixed-size detection records to rank 0"): the
+ * `batch` records of each of `nslots` steps (slot s starts at record s * slot_stride_records of d_records, e.g. a ring
+ * set with ffgpu_exec_set_ring) are packed into nslots blocks of ffgpu_packed_records_bytes(batch, cap) bytes:
+ *     int total, over, batch, cap | { int count, ncand, overflow, first } x batch | BBOX box[cap]
+ * boxes of the frames behind each other in frame order.  A step with more than `cap` boxes keeps the first `cap`
+ * (over = 1, overflow |= 2 on the frames that lost boxes).  ffcnn_amd/dist.py unpacks them on the host. */
+size_t ffgpu_packed_records_bytes(int batch, int cap);
+int    ffgpu_pack_records(const void *d_records, int nslots, long slot_stride_records, int batch, int cap, void *d_out, void *stream);
+
 /* the same question with hand-placed instruction streams: mode 0 = 16 MFMAs per trip; 1 = each followed by `ns` plain
  * v_fma_f32; 2 = by ns/2 v_pk_fma_f32; 3 / 4 = the vector instructions alone.  Microseconds per launch. */
 float ffgpu_pipe_probe2(int mode, int ns, int blocks, int iters, void *stream);

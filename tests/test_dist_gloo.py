@@ -135,3 +135,98 @@ def test_record_ring_groups_gloo(steps, M):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0] is True
+
+
+# ---- compact records: the numpy mirror of ffgpu_pack_records packs / unpacks without loss, truncates with flags, and a
+# partial group of packed steps travels through a two-rank gather
+def _random_records(rng, batch, max_per_frame):
+    recs = np.zeros(batch, DETS_DTYPE)
+    for n in range(batch):
+        c = int(rng.integers(0, max_per_frame + 1))
+        recs[n]["count"], recs[n]["ncand"], recs[n]["overflow"] = c, c + int(rng.integers(0, 5)), 0
+        for k in range(c):
+            recs[n]["box"][k] = (int(rng.integers(0, 80)), rng.random(), *(rng.random(4) * 320).tolist())
+    return recs
+
+
+def test_pack_unpack_records():
+    rng = np.random.default_rng(5)
+    for batch, per, cap in ((64, 3, 1024), (4, 6, 64), (7, 0, 8), (5, 9, 10), (3, 4, 1)):
+        recs = _random_records(rng, batch, per)
+        blk = ffdist.pack_records(recs, cap)
+        assert len(blk) == ffdist.packed_bytes(batch, cap) and len(blk) % 16 == 0
+        back = ffdist.unpack_records(blk, DETS_DTYPE)
+        total = int(recs["count"].sum())
+        hdr = blk[:16].view(np.int32)
+        assert tuple(hdr) == (min(total, cap), int(total > cap), batch, cap)
+        if total <= cap:
+            assert back.tobytes() == recs.tobytes()
+        else:
+            assert int(back["count"].sum()) == cap
+            lost = back["count"] < recs["count"]
+            assert lost.any() and ((back["overflow"] & 2) != 0).tolist() == lost.tolist()
+            first = 0
+            for n in range(batch):                                  # what is kept is a prefix of every frame's boxes, in frame order
+                k = int(back[n]["count"])
+                assert back[n]["box"][:k].tobytes() == recs[n]["box"][:k].tobytes()
+                assert k == max(0, min(int(recs[n]["count"]), cap - first))
+                first += int(recs[n]["count"])
+
+
+def _packed_worker(rank, world, port, steps, M, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        batch, cap = 6, 24
+        pb = ffdist.packed_bytes(batch, cap)
+        rng = np.random.default_rng(100 + rank)
+        mine = [_random_records(rng, batch, 5) for _ in range(steps)]
+        cring = torch.zeros((2, M, pb), dtype=torch.uint8)
+        out = [torch.empty(M * pb, dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
+        seen = {}
+
+        def ship(g, n_valid, first_step):                          # only the written slots travel (bench.py's flush)
+            nb = n_valid * pb
+            got = ffdist.gather_records(dist, cring[g].view(-1)[:nb], dst=0, out=[t[:nb] for t in out] if out else None)
+            if rank == 0:
+                for s, per_rank in enumerate(ffdist.unpack_group([t.numpy() for t in got], n_valid, pb)):
+                    seen[first_step + s] = [ffdist.unpack_records(b, DETS_DTYPE) for b in per_rank]
+
+        for i in range(steps):
+            g, slot = ffdist.ring_slot(i, M)
+            cring[g, slot] = torch.from_numpy(ffdist.pack_records(mine[i], cap))
+            if ffdist.group_due(i, M):
+                ship(g, M, i - M + 1)
+        if steps % M:
+            ship(ffdist.ring_slot(steps, M)[0], steps % M, steps - steps % M)
+        ok = None
+        if rank == 0:
+            ok = sorted(seen) == list(range(steps))
+            for r in range(world):
+                ref = [_random_records(np.random.default_rng(100 + r), batch, 5)]
+                gen = np.random.default_rng(100 + r)
+                for i in range(steps):
+                    want = _random_records(gen, batch, 5)
+                    w2 = ffdist.unpack_records(ffdist.pack_records(want, cap), DETS_DTYPE)
+                    ok = ok and seen[i][r].tobytes() == w2.tobytes()
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps,M", [(5, 4), (8, 4), (3, 8)])
+def test_packed_record_groups_gloo(steps, M):
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_packed_worker, args=(r, world, port, steps, M, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] is True

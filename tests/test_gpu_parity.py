@@ -329,6 +329,43 @@ def test_forward_dev_torch_stream(F, net, frames, oracle_runs):
             boxes_match(ex.boxes(f, dets), oracle_runs[f]["boxes"], "frame %d" % f)
 
 
+def test_packed_records(F, net, frames, oracle_runs):
+    """ffgpu_pack_records (what the multi-GPU gather moves) == its numpy mirror, and unpacking gives the records back;
+    a step with more boxes than the budget keeps the first ones and flags the rest"""
+    import torch
+    from ffcnn_amd import dist as ffdist
+    with net.executor(4, 0) as ex:
+        rec_bytes = F.DETS_DTYPE.itemsize * 4
+        ring = torch.zeros((3, rec_bytes), dtype=torch.uint8, device="cuda")
+        ex.set_ring(ring.data_ptr(), 3)
+        for fr in (frames, frames[::-1].copy(), frames):
+            ex.forward_host(fr)
+        torch.cuda.synchronize()
+        full = np.frombuffer(ring.cpu().numpy().tobytes(), F.DETS_DTYPE).reshape(3, 4)
+        assert full["count"].sum() > 0
+        for cap in (64, 5, 1):
+            pb = F.packed_records_bytes(4, cap)
+            assert pb == ffdist.packed_bytes(4, cap)
+            out = torch.full((3, pb), 0xAB, dtype=torch.uint8, device="cuda")
+            F.pack_records_dev(ring.data_ptr(), 3, 4, 4, cap, out.data_ptr())
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            for s in range(3):
+                want = ffdist.pack_records(full[s], cap)
+                hdr = got[s][:16].view(np.int32)
+                nb = 16 + 16 * 4 + 24 * int(hdr[0])                 # header, frame table and the boxes that exist
+                assert got[s][:nb].tobytes() == want[:nb].tobytes(), (cap, s)
+                back = ffdist.unpack_records(got[s], F.DETS_DTYPE)
+                total = int(full[s]["count"].sum())
+                assert int(hdr[1]) == (total > cap)
+                if total <= cap:
+                    for n in range(4):
+                        assert back[n]["count"] == full[s][n]["count"] and back[n]["ncand"] == full[s][n]["ncand"]
+                        assert back[n]["box"][: back[n]["count"]].tobytes() == full[s][n]["box"][: full[s][n]["count"]].tobytes()
+                else:
+                    assert int(back["count"].sum()) == cap and (back["overflow"] & 2).any()
+
+
 def test_front_kernel_layers(F, net, frames, oracle_runs, monkeypatch):
     """first layer + first thin block as one kernel (k_front; forced on a small batch): its output (layer 3) and everything
     behind it against the oracle, frame by frame; the tensor it no longer writes (layer 0) must refuse to be read"""
