@@ -12,6 +12,8 @@ SEG = [("none", None), ("layer 0", (0, 0)), ("thin blocks 1-8", (1, 8)), ("160->
        ("80->40 s2 22-24", (22, 24)), ("40x40x48 25-37", (25, 37)), ("40x40x96 38-57", (38, 57)), ("40->20 s2 58-60", (58, 60)),
        ("20x20 61-80", (61, 80)), ("20->10 s2 81-83", (81, 83)), ("10x10 84-108", (84, 108)), ("SPP 109-114", (109, 114)),
        ("head 10x10 115-121", (115, 121)), ("head 20x20 122-130", (122, 130)), ("none", None)]
+if len(sys.argv) > 1:                      # custom stretches: python tools/ablate_layers.py 123:123 125:125 ...
+    SEG = [("none", None)] + [("layers " + a, tuple(int(v) for v in a.split(":"))) for a in sys.argv[1:]] + [("none", None)]
 base = None
 for name, rng in SEG:
     if rng:
