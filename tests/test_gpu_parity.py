@@ -329,6 +329,27 @@ def test_forward_dev_torch_stream(F, net, frames, oracle_runs):
             boxes_match(ex.boxes(f, dets), oracle_runs[f]["boxes"], "frame %d" % f)
 
 
+def test_executor_life_cycle_frees_device_memory(F, net, frames):
+    """create / forward / destroy: device memory in use must not grow (a graph with a forked branch kept its arena's worth
+    of memory per cycle until ffgpu_exec_destroy synchronised the device first)"""
+    import torch
+
+    def used():
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info()
+        return total - free
+
+    marks = {}
+    for it in range(12):
+        for flags in (0, F.FFGPU.HOST_DETS, F.FFGPU.SPLIT2):
+            with net.executor(4, flags) as ex:
+                ex.forward_host(frames)
+                ex.read_dets()
+        if it in (3, 11):
+            marks[it] = used()
+    assert marks[11] - marks[3] < 4 << 20, "device memory grew by %.1f MB over 8 cycles" % ((marks[11] - marks[3]) / 1e6)
+
+
 def test_packed_records(F, net, frames, oracle_runs):
     """ffgpu_pack_records (what the multi-GPU gather moves) == its numpy mirror, and unpacking gives the records back;
     a step with more boxes than the budget keeps the first ones and flags the rest"""
