@@ -507,6 +507,10 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
     // tuning only (tools/ablate_layers.py): FFGPU_DBG_SKIP="lo:hi" drops the launches of layers lo..hi -- wrong results,
     // but the change in frames/s is what that stretch of the net costs with several batches in flight
     // (FFGPU_DBG_KEEP="lo:hi" is the complement: only that stretch runs -- tools/saturate_layers.py)
+    if (getenv("FFGPU_DBG_SKIP") || getenv("FFGPU_DBG_KEEP")) {
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "libffcnn_hip: FFGPU_DBG_SKIP / FFGPU_DBG_KEEP set -- launches are being dropped, RESULTS ARE WRONG (tuning only)\n"); }
+    }
     if (const char *sk = getenv("FFGPU_DBG_SKIP")) {
         int lo = -1, hi = -1;
         if (sscanf(sk, "%d:%d", &lo, &hi) == 2 && st.layer >= lo && st.layer <= hi && st.kind != S_NMS) return 0;
