@@ -76,25 +76,6 @@ def packed_bytes(batch, cap, box_bytes=24):
     return (16 + 16 * batch + box_bytes * cap + 15) & ~15
 
 
-def pack_records(recs, cap):
-    """numpy mirror of the device kernel: recs = structured array (count, ncand, overflow, reserved, box[MAX_DET]) of one step."""
-    batch = len(recs)
-    box_dtype = recs.dtype["box"].subdtype[0]
-    out = np.zeros(packed_bytes(batch, cap, box_dtype.itemsize), np.uint8)
-    hdr = out[:16].view(np.int32)
-    fr = out[16:16 + 16 * batch].view(np.int32).reshape(batch, 4)
-    box = out[16 + 16 * batch:16 + 16 * batch + box_dtype.itemsize * cap].view(box_dtype)
-    first = 0
-    for n in range(batch):
-        cnt = int(recs[n]["count"])
-        kept = max(0, min(cnt, cap - first))
-        fr[n] = (kept, recs[n]["ncand"], int(recs[n]["overflow"]) | (2 if kept < cnt else 0), min(first, cap))
-        box[min(first, cap):min(first, cap) + kept] = recs[n]["box"][:kept]
-        first += cnt
-    hdr[:] = (min(first, cap), int(first > cap), batch, cap)
-    return out
-
-
 def unpack_records(block, dets_dtype):
     """one step's packed block (bytes / uint8 array) -> structured array of `batch` full-size records (unused boxes zero)."""
     b = np.frombuffer(bytes(block), np.uint8)

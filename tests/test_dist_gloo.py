@@ -11,6 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from ffcnn_amd import dist as ffdist
+from packref import pack_records
 from ffcnn_amd.capi import DETS_DTYPE, FFGPU
 
 
@@ -153,7 +154,7 @@ def test_pack_unpack_records():
     rng = np.random.default_rng(5)
     for batch, per, cap in ((64, 3, 1024), (4, 6, 64), (7, 0, 8), (5, 9, 10), (3, 4, 1)):
         recs = _random_records(rng, batch, per)
-        blk = ffdist.pack_records(recs, cap)
+        blk = pack_records(recs, cap)
         assert len(blk) == ffdist.packed_bytes(batch, cap) and len(blk) % 16 == 0
         back = ffdist.unpack_records(blk, DETS_DTYPE)
         total = int(recs["count"].sum())
@@ -194,7 +195,7 @@ def _packed_worker(rank, world, port, steps, M, q):
 
         for i in range(steps):
             g, slot = ffdist.ring_slot(i, M)
-            cring[g, slot] = torch.from_numpy(ffdist.pack_records(mine[i], cap))
+            cring[g, slot] = torch.from_numpy(pack_records(mine[i], cap))
             if ffdist.group_due(i, M):
                 ship(g, M, i - M + 1)
         if steps % M:
@@ -207,7 +208,7 @@ def _packed_worker(rank, world, port, steps, M, q):
                 gen = np.random.default_rng(100 + r)
                 for i in range(steps):
                     want = _random_records(gen, batch, 5)
-                    w2 = ffdist.unpack_records(ffdist.pack_records(want, cap), DETS_DTYPE)
+                    w2 = ffdist.unpack_records(pack_records(want, cap), DETS_DTYPE)
                     ok = ok and seen[i][r].tobytes() == w2.tobytes()
         q.put((rank, ok))
     finally:

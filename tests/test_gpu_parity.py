@@ -355,6 +355,7 @@ def test_packed_records(F, net, frames, oracle_runs):
     a step with more boxes than the budget keeps the first ones and flags the rest"""
     import torch
     from ffcnn_amd import dist as ffdist
+    from packref import pack_records
     with net.executor(4, 0) as ex:
         rec_bytes = F.DETS_DTYPE.itemsize * 4
         ring = torch.zeros((3, rec_bytes), dtype=torch.uint8, device="cuda")
@@ -372,7 +373,7 @@ def test_packed_records(F, net, frames, oracle_runs):
             torch.cuda.synchronize()
             got = out.cpu().numpy()
             for s in range(3):
-                want = ffdist.pack_records(full[s], cap)
+                want = pack_records(full[s], cap)
                 hdr = got[s][:16].view(np.int32)
                 nb = 16 + 16 * 4 + 24 * int(hdr[0])                 # header, frame table and the boxes that exist
                 assert got[s][:nb].tobytes() == want[:nb].tobytes(), (cap, s)
