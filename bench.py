@@ -264,10 +264,9 @@ def main():
     gather_mode = world > 1 or args.force_gather
     host_dets = not gather_mode
     # Batches are independent, so consecutive steps go to S executors on S streams in turn (each its own arena and graph,
-    # no events between them): while one batch is in its latency-bound tail (10x10 / 20x20 planes) the next one is in its
-    # throughput-bound head, and the two use the chip in a complementary way -- 0.71 ms per 64 frames with one chain,
-    # 0.66 with FFGPU_SPLIT2 (two half-batch chains in lockstep), 0.49 / 0.46 with two / three whole-batch chains
-    # (tools/split_batch.py).  The head branch inside a chain is off here: more chains do its job with fewer forks.
+    # no events between them).  The chains run in lockstep (tools/ramp.py): S copies of every launch are on the device
+    # together and fill the SIMDs that one 64-frame launch leaves idle -- 0.69 ms per 64 frames with one chain, 0.44 with
+    # two, 0.36 with four.  The head branch inside a chain is off here.
     S = max(1, args.streams)
     if gather_mode and 2 * max(1, args.gather_every) % S:
         raise SystemExit("--gather-every * 2 must be a multiple of --streams")
