@@ -159,13 +159,13 @@ def kernel_roofline(torch, capi, stream):
     # back-to-back series runs 560, 550, ..., 765 us around the 7th launch, then decays to a steady 550 us by the
     # 50th).  That transient is power management, not the kernel, so the timed region starts after 64 bare copies of
     # the same tensors (another kernel, so rocprofv3's per-kernel average of this command matches the number below).
-    capi.lib().ffgpu_membench(y.data_ptr(), x.data_ptr(), alg_bytes // 2, 0, 1024, 64, stream.cuda_stream)
+    capi.diag().ffgpu_membench(y.data_ptr(), x.data_ptr(), alg_bytes // 2, 0, 1024, 64, stream.cuda_stream)
     us = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, Cc, Cc, 1, 1, 3, Cc, act=2,
                                  warmup=4, iters=50, stream=stream.cuda_stream)
     name = capi.kernel_name(N, W, H, Cc, Cc, 1, 1, 3, Cc)
     # context: what a bare 16-byte copy / read of the same bytes reaches on THIS GPU (ffgpu_membench)
-    copy_us = min(capi.lib().ffgpu_membench(y.data_ptr(), x.data_ptr(), alg_bytes // 2, 0, b, 10, stream.cuda_stream) for b in (1024, 2048))
-    read_us = capi.lib().ffgpu_membench(y.data_ptr(), x.data_ptr(), alg_bytes // 2, 2, 2048, 10, stream.cuda_stream)
+    copy_us = min(capi.diag().ffgpu_membench(y.data_ptr(), x.data_ptr(), alg_bytes // 2, 0, b, 10, stream.cuda_stream) for b in (1024, 2048))
+    read_us = capi.diag().ffgpu_membench(y.data_ptr(), x.data_ptr(), alg_bytes // 2, 2, 2048, 10, stream.cuda_stream)
     gbs = alg_bytes / (us * 1e-6) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "dw3x3_traffic.json")     # per-launch HBM bytes from the PMC passes

@@ -16,9 +16,8 @@ f32p = C.POINTER(C.c_float)
 
 class FFGPU:
     MAX_DET = 128
-    MAX_CAND = 1024
     KEEP_ALL, COMPAT_V6, NO_GRAPH, NO_FUSE, HOST_DETS, SPLIT2, CONCURRENT = 1, 2, 4, 8, 16, 32, 64
-    K_AUTO, K_GENERIC, K_DW_STREAM, K_DW_LDS, K_PW_MFMA, K_PW_GEMM, K_PW_VALU, K_DENSE_SMALL = range(8)
+    K_AUTO, K_GENERIC, K_DW_STREAM, K_DW_LDS, K_PW_MFMA, K_PW_GEMM, _K6, K_DENSE_SMALL, K_IGEMM = range(9)
 
 
 class LAYER(C.Structure):            # include/ffcnn.h (120 bytes)
@@ -45,7 +44,7 @@ class NET(C.Structure):              # 104 bytes
 
 
 class FrameDets(C.Structure):        # ffgpu_frame_dets
-    _fields_ = [("count", C.c_int), ("ncand", C.c_int), ("overflow", C.c_int), ("reserved", C.c_int),
+    _fields_ = [("count", C.c_int), ("ncand", C.c_int), ("overflow", C.c_int), ("nfull", C.c_int),
                 ("box", BBOX * FFGPU.MAX_DET)]
 
 
@@ -53,7 +52,7 @@ assert C.sizeof(LAYER) == 120 and C.sizeof(NET) == 104 and C.sizeof(BBOX) == 24
 assert C.sizeof(FrameDets) == 16 + 24 * FFGPU.MAX_DET
 
 BOX_DTYPE = np.dtype([("type", "<i4"), ("score", "<f4"), ("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4")])
-DETS_DTYPE = np.dtype([("count", "<i4"), ("ncand", "<i4"), ("overflow", "<i4"), ("reserved", "<i4"),
+DETS_DTYPE = np.dtype([("count", "<i4"), ("ncand", "<i4"), ("overflow", "<i4"), ("nfull", "<i4"),
                        ("box", BOX_DTYPE, (FFGPU.MAX_DET,))])
 
 # every symbol include/*.h declares; tests check the built library exports all of them
@@ -63,7 +62,10 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_create", "ffgpu_exec_destroy", "ffgpu_exec_batch", "ffgpu_exec_arena_bytes",
            "ffgpu_exec_kernel_count", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
            "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_set_ring", "ffgpu_exec_set_ring_strided", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
-           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_pipe_probe2", "ffgpu_irb_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records"]
+           "ffgpu_exec_read_boxes", "ffgpu_exec_cand_capacity", "ffgpu_exec_graph_captures",
+           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records"]
+# include/ffcnn_hip_diag.h (libffcnn_hip_diag.so: lab equipment, its own library)
+DIAG_EXPORTS = ["ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_pipe_probe2"]
 
 
 def library_path():
@@ -132,18 +134,38 @@ def lib():
     L.ffgpu_groupconv_time_dev.argtypes = [vp, vp, vp] + [i] * 17 + [vp]
     L.ffgpu_irb_dev.restype = C.c_float
     L.ffgpu_irb_dev.argtypes = [vp] * 6 + [i] * 13 + [vp]
-    L.ffgpu_membench.restype = C.c_float
-    L.ffgpu_membench.argtypes = [vp, vp, sz, i, i, i, vp]
-    L.ffgpu_pipe_probe.restype = C.c_float
-    L.ffgpu_pipe_probe.argtypes = [i, i, i, i, vp]
+    L.ffgpu_exec_read_boxes.argtypes = [vp, i, vp, i]
+    L.ffgpu_exec_cand_capacity.argtypes = [vp]
+    L.ffgpu_exec_graph_captures.argtypes = [vp]
     L.ffgpu_packed_records_bytes.restype = C.c_size_t
     L.ffgpu_packed_records_bytes.argtypes = [i, i]
     L.ffgpu_pack_records.restype = i
     L.ffgpu_pack_records.argtypes = [vp, i, C.c_long, i, i, vp, vp]
-    L.ffgpu_pipe_probe2.restype = C.c_float
-    L.ffgpu_pipe_probe2.argtypes = [i, i, i, i, vp]
     _lib = L
     return L
+
+
+_diag = None
+
+
+def diag_path():
+    return os.path.join(HERE, "lib", "libffcnn_hip_diag.so")
+
+
+def diag():
+    """libffcnn_hip_diag.so (include/ffcnn_hip_diag.h): HBM stream calibration and pipe probes; not the product."""
+    global _diag
+    if _diag is None:
+        D = C.CDLL(diag_path())
+        vp, i, sz = C.c_void_p, C.c_int, C.c_size_t
+        D.ffgpu_membench.restype = C.c_float
+        D.ffgpu_membench.argtypes = [vp, vp, sz, i, i, i, vp]
+        D.ffgpu_pipe_probe.restype = C.c_float
+        D.ffgpu_pipe_probe.argtypes = [i, i, i, i, vp]
+        D.ffgpu_pipe_probe2.restype = C.c_float
+        D.ffgpu_pipe_probe2.argtypes = [i, i, i, i, vp]
+        _diag = D
+    return _diag
 
 
 def load_bmp(path):
@@ -359,8 +381,22 @@ class Executor:
         _check(lib().ffgpu_exec_read_layer(self.h, layer, frame, out.ctypes.data_as(f32p), out.size), "ffgpu_exec_read_layer")
         return out
 
+    @property
+    def cand_capacity(self):
+        return lib().ffgpu_exec_cand_capacity(self.h)
+
+    @property
+    def graph_captures(self):
+        return lib().ffgpu_exec_graph_captures(self.h)
+
+    def read_boxes(self, frame=0):
+        """every box of `frame` that survived NMS (the record keeps the first FFGPU.MAX_DET)"""
+        out = np.zeros(max(1, self.cand_capacity), BOX_DTYPE)
+        n = _check(lib().ffgpu_exec_read_boxes(self.h, frame, out.ctypes.data, out.size), "ffgpu_exec_read_boxes")
+        return out[:n].copy()
+
     def read_candidates(self, frame=0):
-        out = np.zeros(FFGPU.MAX_CAND, BOX_DTYPE)
+        out = np.zeros(max(1, self.cand_capacity), BOX_DTYPE)
         n = _check(lib().ffgpu_exec_read_layer(self.h, -2, frame, out.ctypes.data_as(f32p), out.size * 6), "read candidates")
         return out[:n].copy()
 

@@ -228,6 +228,7 @@ static void read_weights(NET *net, const char *path)
 {
     FILE *fp = path ? fopen(path, "rb") : NULL;
     float *row0 = net->weight_buf;
+    int short_warned = 0;
     if (fp) fseek(fp, 20, SEEK_SET);
     for (int i = 0; i < net->layer_num; i++) {
         LAYER *l = net->layer_list + i;
@@ -237,7 +238,7 @@ static void read_weights(NET *net, const char *path)
         l->filter = row0;
         row0 += (size_t)l->fn * rl;
         if (!fp) continue;
-        size_t got = 0;
+        size_t got = 0, want = (size_t)l->fn * (size_t)(1 + (l->batchnorm ? 3 : 0) + taps);
         for (int j = 0; j < l->fn; j++) { tail[j * rl] = 1.0f; got += fread(&tail[j * rl + 1], sizeof(float), 1, fp); }
         if (l->batchnorm) {
             static const int slot[3] = { 0, 2, 3 };             /* scale, mean, variance */
@@ -250,7 +251,12 @@ static void read_weights(NET *net, const char *path)
             }
         }
         for (int j = 0; j < l->fn; j++) got += fread(l->filter + (size_t)j * rl, sizeof(float), (size_t)taps, fp);
-        (void)got;
+        /* the reference ignores short reads too (ffcnn.c:211-235) and runs on with zero filters; say so at least */
+        if (got != want && !short_warned) {
+            short_warned = 1;
+            fprintf(stderr, "ffcnn: weights file '%s' ends inside layer %d (%zu of %zu floats): remaining filters stay zero\n",
+                    path, i, got, want);
+        }
     }
     if (fp) fclose(fp);
 }
@@ -276,9 +282,9 @@ NET *net_load(char *cfg_path, char *weights_path, int inputw, int inputh)
     size_t in_floats = (size_t)l0->w * l0->h * l0->c;
     net->weight_buf = (float *)calloc(net->weight_size > 0 ? (size_t)net->weight_size : 1, sizeof(float));
     l0->data = (float *)calloc(in_floats ? in_floats : 1, sizeof(float));
-    net->bbox_max = (int)(in_floats * sizeof(float) / sizeof(BBOX));       /* same capacity as ffcnn.c:243 */
-    if (net->bbox_max > FFGPU_MAX_DET) net->bbox_max = FFGPU_MAX_DET;       /* device record size */
-    ext->own_boxes = (BBOX *)calloc((size_t)FFGPU_MAX_DET, sizeof(BBOX));
+    net->bbox_max = (int)(in_floats * sizeof(float) / sizeof(BBOX));       /* same capacity as ffcnn.c:243 (51 200 at 320x320) */
+    ext->own_boxes = (BBOX *)calloc((size_t)(net->bbox_max > 0 ? net->bbox_max : 1), sizeof(BBOX));
+    ext->box_cap = net->bbox_max > 0 ? net->bbox_max : 1;
     net->bbox_list = ext->own_boxes;
     if (!net->weight_buf || !l0->data || !ext->own_boxes || in_floats == 0) {
         ffgpu_set_error("net_load: allocation failed or empty input geometry");
@@ -336,7 +342,7 @@ void net_forward(NET *net)
     if (!net) return;
     ffcnn_ext *ext = ffcnn_ext_of(net);
     if (!ext || !ext->dev) { fprintf(stderr, "ffcnn: net_forward on a net without device state\n"); return; }
-    if (ffgpu_netdev_forward1(net, ext->dev) != 0)
+    if (ffgpu_netdev_forward1(net, ext->dev, ext->profile) != 0)
         fprintf(stderr, "ffcnn: net_forward failed: %s\n", ffgpu_last_error());
 }
 
@@ -383,5 +389,11 @@ void net_dump(NET *net)
 void net_profile(NET *net)
 {
     if (!net) return;
+    /* same lines as ffcnn.c:550; timeused[] is filled under FFCNN_PROFILE=1 (the reference: ENABLE_NET_PROFILE) from
+     * device time -- whole milliseconds of the time accumulated over all net_forward calls so far */
     for (int k = 0; k < LAYER_TYPE_TOTOAL; k++) printf("%8s: %5d ms\n", kind_name(k), net->timeused[k]);
+    ffcnn_ext *ext = ffcnn_ext_of(net);
+    double us[LAYER_TYPE_TOTOAL];
+    if (ext && ext->profile && ext->dev && getenv("FFCNN_PROFILE_US") && ffgpu_netdev_profile_us(ext->dev, us) == 0)
+        for (int k = 0; k < LAYER_TYPE_TOTOAL; k++) printf("%8s: %9.1f us\n", kind_name(k), us[k]);
 }

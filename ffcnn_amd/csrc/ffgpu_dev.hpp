@@ -20,6 +20,9 @@
 // cs = h*w, ns = C*h*w.
 struct ConvDesc {
     const float *in;
+    const float *const *in_ind;   // optional: device slot holding the input pointer (the executor's parameter block);
+                                  // when set the kernel reads *in_ind instead of `in` -- a captured graph then serves
+                                  // every input buffer.  Only the kernels ffgpu_conv_supports_ind() names honour it.
     const float *filt;     // fn rows of K4+4 floats (conv.h layout)
     float       *out;
     const float *residual; // optional: out = act2(conv_act(...) + residual), same layout as out (fused shortcut)
@@ -56,6 +59,16 @@ int    ffgpu_launch_front(const ConvDesc &c, const IrbDesc &d, hipStream_t s);
 size_t ffgpu_pw_pack_floats(const ConvDesc &d);
 int    ffgpu_pw_pack(const ConvDesc &d, float *pk, hipStream_t s);
 
+// Per-executor parameter block in device memory: what changes from one forward to the next without changing the
+// launch list.  A one-thread kernel (ffgpu_launch_set_params) rewrites it in stream order in front of the graph launch,
+// so ONE instantiated graph serves every input buffer and every box scale (the first round keyed a graph cache on them).
+struct ExecParams {
+    const float *frames;      // this forward's batch input (frame-major N x C x H x W)
+    int s1, s2;               // box rescale ratio (ffcnn.c:267-273), applied by k_nms
+};
+int  ffgpu_launch_set_params(ExecParams *d_prm, const float *frames, int s1, int s2, hipStream_t s);
+bool ffgpu_conv_supports_ind(const ConvDesc &d);    // the kernel ffgpu_launch_conv would pick reads ConvDesc::in_ind
+
 // kernels.hip
 int         ffgpu_launch_conv(const ConvDesc &d, int variant, hipStream_t s);
 const char *ffgpu_conv_kernel_name(const ConvDesc &d, int variant);
@@ -74,8 +87,15 @@ struct YoloHead {
     float thresh, scale_xy;
     int   key_base;        // emission-order key of this head's first candidate
 };
-int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, int *ring_ctr, hipStream_t s);
-int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
+// cand / cand_key: `cap` slots per frame (cap = 3 * cells summed over the heads: every anchor of every cell has a slot, so
+// the decode never drops a candidate -- the reference's buffer holds bbox_max = 51 200 of them, ffcnn.c:243,463)
+int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, int cap, int *ring_ctr, hipStream_t s);
+// full (may be NULL): cap boxes per frame, ALL survivors in score order (the fixed-size record keeps the first FFGPU_MAX_DET)
+// bbox_max: the reference stops appending candidates at net->bbox_max in emission order (ffcnn.c:463); same here
+// scratch (cap_pow2 > FFGPU_NMS_LDS_CAP only): 12 bytes x cap_pow2 per frame of global memory instead of LDS
+int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, int bbox_max, BBOX *full, void *scratch,
+                     ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
                      ffgpu_frame_dets *ring, int ring_slots, int ring_stride, const int *ring_ctr, int N,
-                     float thresh, int use_min, int s1, int s2, hipStream_t s);
+                     float thresh, int use_min, const ExecParams *prm, hipStream_t s);
+#define FFGPU_NMS_LDS_CAP 8192
 int ffgpu_launch_clear(int *ncand, int N, int *ring_ctr, hipStream_t s);

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -90,7 +91,9 @@ struct Tensor {
 
 struct ffgpu_netdev {
     NET   *net = nullptr;
-    std::vector<ffgpu_exec *> execs;   // executors holding packings derived from d_weights
+    std::mutex mu;                     // guards execs (executors may be created / destroyed from several threads)
+    std::vector<ffgpu_exec *> execs;   // every live executor of this net (they hold packings derived from d_weights)
+    double us_acc[LAYER_TYPE_TOTOAL] = {};   // FFCNN_PROFILE=1: device time per layer kind, accumulated over net_forward calls
     float *d_weights = nullptr;
     size_t weight_bytes = 0;
     int    device = 0;
@@ -110,8 +113,15 @@ struct ffgpu_exec {
     size_t arena_floats = 0;
     float *d_input = nullptr;          // own staging buffer for host / bgr entry points
     float *d_pack = nullptr;           // packed constants of the fused blocks (derived from the weights)
-    BBOX  *d_cand = nullptr;
+    BBOX  *d_cand = nullptr;           // cand_cap candidate slots per frame: one per anchor of every head cell
     int   *d_cand_key = nullptr, *d_ncand = nullptr;
+    int    cand_cap = 1, bbox_max = 1;
+    BBOX  *d_full = nullptr;           // every box that survives NMS, score order, cand_cap slots per frame
+    void  *d_nms_scratch = nullptr;    // k_nms work arrays when they do not fit LDS
+    ExecParams *d_prm = nullptr;       // device parameter block: input pointer + box scale of the forward being enqueued
+    bool   indirect = false;           // every launch that reads the batch input does so through d_prm->frames
+    const float *prm_frames = nullptr; int prm_s1 = 0, prm_s2 = 0; hipStream_t prm_stream = nullptr; bool prm_valid = false;
+    const float *last_frames = nullptr;   // input of the last forward (read_layer(-1))
     ffgpu_frame_dets *d_dets = nullptr;
     ffgpu_frame_dets *h_dets = nullptr, *h_dets_dev = nullptr;   // FFGPU_HOST_DETS: pinned mirror and its device address
     ffgpu_frame_dets *ring = nullptr; int ring_slots = 0; int *d_ringctr = nullptr;   // ffgpu_exec_set_ring
@@ -126,10 +136,14 @@ struct ffgpu_exec {
     hipStream_t side_stream = nullptr;              // second graph branch
     hipEvent_t  ev_fork = nullptr, ev_join = nullptr;
     int side_lo = -1, side_hi = -1;                 // layers [side_lo, side_hi] form the side branch
-    // graph cache: one instantiated graph per (input pointer, s1, s2)
-    struct GraphKey { const float *in; int s1, s2; bool operator<(const GraphKey &o) const {
-        return in != o.in ? in < o.in : s1 != o.s1 ? s1 < o.s1 : s2 < o.s2; } };
-    std::map<GraphKey, hipGraphExec_t> graphs;
+    // ONE instantiated graph per executor: the input pointer and the box scale reach the kernels through d_prm.  Only a
+    // net whose first layer has no kernel that reads through the slot (indirect == false: e.g. a pool or a pointwise conv
+    // straight on the input) falls back to graphs keyed by the input pointer, least recently used one evicted.
+    hipGraphExec_t graph1 = nullptr;
+    struct Keyed { const float *in; hipGraphExec_t g; unsigned long stamp; };
+    std::vector<Keyed> graphs;
+    unsigned long graph_stamp = 0;
+    int captures = 0;                  // graphs captured + instantiated so far (ffgpu_exec_graph_captures)
     int kernel_count = 0;
 };
 
@@ -487,6 +501,14 @@ static int plan(ffgpu_exec *ex)
     }
     { Step nm{}; nm.kind = S_NMS; nm.layer = -1; nm.ltype = LAYER_TYPE_YOLO; S.push_back(nm); }
     for (Step &st : S) st.lane = (ex->side_lo >= 0 && st.layer >= ex->side_lo && st.layer <= ex->side_hi) ? 1 : 0;
+    // launches that read the batch input take its address from the parameter block when their kernel can (the first conv
+    // of every darknet cfg: dense KxK from 3 channels): the captured graph is then independent of the input buffer
+    ex->indirect = true;
+    for (const Step &st : S)
+        if (st.in_is_input && !(st.kind == S_FRONT || (st.kind == S_CONV && ffgpu_conv_supports_ind(st.conv)))) ex->indirect = false;
+    if (getenv("FFGPU_NO_INDIRECT") && atoi(getenv("FFGPU_NO_INDIRECT"))) ex->indirect = false;      // tests: the keyed fallback
+    if (ex->indirect)
+        for (Step &st : S) if (st.in_is_input) st.conv.in_ind = reinterpret_cast<const float *const *>(ex->d_prm);   // &d_prm->frames
     ex->kernel_count = (int)S.size();
     (void)nheads;
     return 0;
@@ -504,6 +526,7 @@ static int repack(ffgpu_exec *ex, hipStream_t s)
 // -------------------------------------------------------------------------- running
 static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hipStream_t s)
 {
+#ifdef FFGPU_DIAG
     // tuning only (tools/ablate_layers.py): FFGPU_DBG_SKIP="lo:hi" drops the launches of layers lo..hi -- wrong results,
     // but the change in frames/s is what that stretch of the net costs with several batches in flight
     // (FFGPU_DBG_KEEP="lo:hi" is the complement: only that stretch runs -- tools/saturate_layers.py)
@@ -519,12 +542,13 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
         int lo = -1, hi = -1;
         if (sscanf(sk, "%d:%d", &lo, &hi) == 2 && (st.layer < lo || st.layer > hi) && st.kind != S_NMS) return 0;
     }
+#endif
     switch (st.kind) {
     case S_CLEAR:
         return ffgpu_launch_clear(ex->d_ncand, ex->N, ex->ring ? ex->d_ringctr : nullptr, s);
     case S_CONV: {
         ConvDesc d = st.conv;
-        if (st.in_is_input) d.in = d_frames;
+        if (st.in_is_input && !d.in_ind) d.in = d_frames;
         return ffgpu_launch_conv(d, FFGPU_K_AUTO, s); }
     case S_POOL:
         if (st.fs2[0]) {
@@ -551,13 +575,15 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
         return ffgpu_launch_irb(st.irb, s);
     case S_FRONT: {
         ConvDesc d = st.conv;
-        if (st.in_is_input) d.in = d_frames;
+        if (st.in_is_input && !d.in_ind) d.in = d_frames;
         return ffgpu_launch_front(d, st.irb, s); }
     case S_YOLO:
-        return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand,
+        return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->cand_cap,
                                  (st.flag && ex->ring) ? ex->d_ringctr : nullptr, s);
     case S_NMS:
-        return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->d_dets, ex->h_dets_dev, ex->ring, ex->ring_slots, ex->ring_stride ? ex->ring_stride : ex->N, ex->d_ringctr, ex->N, 0.5f, 1, ex->s1, ex->s2, s);
+        return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->cand_cap, ex->bbox_max, ex->d_full, ex->d_nms_scratch,
+                                ex->d_dets, ex->h_dets_dev, ex->ring, ex->ring_slots, ex->ring_stride ? ex->ring_stride : ex->N,
+                                ex->d_ringctr, ex->N, 0.5f, 1, ex->d_prm, s);
     }
     return -1;
 }
@@ -607,40 +633,100 @@ static int issue_split(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
     return 0;
 }
 
+// the parameter block of this forward, written in stream order in front of the launches that read it; skipped when the
+// block already holds (or, on the same stream, will hold by then) the same values
+static int push_params(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
+{
+    if (ex->child[0]) {
+        const size_t part = (size_t)ex->child[0]->N * ex->in_c * ex->in_h * ex->in_w;
+        for (int c = 0; c < ex->nchild; c++) {
+            ex->child[c]->s1 = ex->s1; ex->child[c]->s2 = ex->s2; ex->child[c]->last_stream = s;
+            if (push_params(ex->child[c], d_frames + c * part, s)) return -1;
+        }
+        return 0;
+    }
+    ex->last_frames = d_frames;
+    if (ex->prm_valid && ex->prm_frames == d_frames && ex->prm_s1 == ex->s1 && ex->prm_s2 == ex->s2 && ex->prm_stream == s) return 0;
+    if (ffgpu_launch_set_params(ex->d_prm, d_frames, ex->s1, ex->s2, s)) return -1;
+    ex->prm_frames = d_frames; ex->prm_s1 = ex->s1; ex->prm_s2 = ex->s2; ex->prm_stream = s; ex->prm_valid = true;
+    return 0;
+}
+
+static bool graph_pointer_free(const ffgpu_exec *ex)
+{
+    if (!ex->child[0]) return ex->indirect;
+    for (int c = 0; c < ex->nchild; c++) if (!ex->child[c]->indirect) return false;
+    return true;
+}
+
+static int capture(ffgpu_exec *ex, const float *d_frames, hipGraphExec_t *out)
+{
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    // capture on the executor's own stream (a user stream may be the legacy
+    // null stream, which cannot be captured); replay goes to the caller's stream
+    hipStream_t cs = ex->own_stream;
+    FFGPU_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    const int rc = ex->child[0] ? issue_split(ex, d_frames, cs) : issue_all(ex, d_frames, cs);
+    hipError_t e = hipStreamEndCapture(cs, &graph);
+    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return -1; }
+    if (e != hipSuccess) { ffgpu_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return -1; }
+    e = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { ffgpu_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return -1; }
+    ex->captures++;
+    *out = gexec;
+    return 0;
+}
+
+static void drop_graphs(ffgpu_exec *ex)                       // caller has synchronised the streams the graphs ran on
+{
+    if (ex->graph1) { (void)hipGraphExecDestroy(ex->graph1); ex->graph1 = nullptr; }
+    for (auto &g : ex->graphs) (void)hipGraphExecDestroy(g.g);
+    ex->graphs.clear();
+}
+
 static int forward_on(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
 {
     ex->last_stream = s;
-    if (ex->child[0]) {
-        for (int c = 0; c < ex->nchild; c++) { ex->child[c]->s1 = ex->s1; ex->child[c]->s2 = ex->s2; ex->child[c]->last_stream = s; }
-    }
+    if (push_params(ex, d_frames, s)) return -1;
     if (ex->flags & FFGPU_NO_GRAPH) return ex->child[0] ? issue_split(ex, d_frames, s) : issue_all(ex, d_frames, s);
-    ffgpu_exec::GraphKey key{ d_frames, ex->s1, ex->s2 };
-    auto it = ex->graphs.find(key);
-    if (it == ex->graphs.end()) {
-        if (ex->graphs.size() >= 8) {            // bound the cache: drop everything, rebuild on demand
-            for (auto &g : ex->graphs) (void)hipGraphExecDestroy(g.second);
-            ex->graphs.clear();
-        }
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t gexec = nullptr;
-        // capture on the executor's own stream (a user stream may be the legacy
-        // null stream, which cannot be captured); replay goes to `s`
-        hipStream_t cs = ex->own_stream;
-        FFGPU_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-        const int rc = ex->child[0] ? issue_split(ex, d_frames, cs) : issue_all(ex, d_frames, cs);
-        hipError_t e = hipStreamEndCapture(cs, &graph);
-        if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return -1; }
-        if (e != hipSuccess) { ffgpu_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return -1; }
-        e = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) { ffgpu_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return -1; }
-        it = ex->graphs.emplace(key, gexec).first;
+    if (graph_pointer_free(ex)) {                            // the usual case: one graph, whatever the input buffer / scale
+        if (!ex->graph1 && capture(ex, d_frames, &ex->graph1)) return -1;
+        FFGPU_CHECK(hipGraphLaunch(ex->graph1, s));
+        return 0;
     }
-    FFGPU_CHECK(hipGraphLaunch(it->second, s));
+    // fallback (the first layer's kernel cannot read through the parameter block): graphs keyed by the input pointer
+    ffgpu_exec::Keyed *hit = nullptr;
+    for (auto &g : ex->graphs) if (g.in == d_frames) hit = &g;
+    if (!hit) {
+        if (ex->graphs.size() >= 8) {                        // evict the least recently used one -- after its last launch ended
+            size_t lru = 0;
+            for (size_t i = 1; i < ex->graphs.size(); i++) if (ex->graphs[i].stamp < ex->graphs[lru].stamp) lru = i;
+            FFGPU_CHECK(hipDeviceSynchronize());             // (it may have run on another stream than this call's)
+            (void)hipGraphExecDestroy(ex->graphs[lru].g);
+            ex->graphs.erase(ex->graphs.begin() + lru);
+        }
+        hipGraphExec_t g = nullptr;
+        if (capture(ex, d_frames, &g)) return -1;
+        ex->graphs.push_back({ d_frames, g, 0 });
+        hit = &ex->graphs.back();
+    }
+    hit->stamp = ++ex->graph_stamp;
+    FFGPU_CHECK(hipGraphLaunch(hit->g, s));
     return 0;
 }
 
 // -------------------------------------------------------------------------- C-ABI: executor
+// an executor whose NET was freed first (net_free orphans it) keeps its device buffers until ffgpu_exec_destroy, but its
+// layer table and weights are gone: every entry point that would touch them fails instead
+static bool alive(const ffgpu_exec *ex, const char *what)
+{
+    if (!ex) { ffgpu_set_error("%s: NULL executor", what); return false; }
+    if (!ex->dev) { ffgpu_set_error("%s: the NET of this executor has been freed (destroy executors before net_free)", what); return false; }
+    return true;
+}
+
 static ffgpu_netdev *netdev_of(NET *net)
 {
     if (!net) { ffgpu_set_error("NULL net"); return nullptr; }
@@ -667,12 +753,26 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
     ffgpu_exec *ex = new ffgpu_exec();
     ex->net = net; ex->dev = dev; ex->N = batch; ex->flags = flags; ex->is_child = as_child;
     ex->in_c = net->layer_list[0].c; ex->in_h = net->layer_list[0].h; ex->in_w = net->layer_list[0].w;
+    // candidate slots per frame: one per anchor of every head cell, so the decode can never overflow; the reference's own
+    // cap (bbox_max candidates in emission order, ffcnn.c:243,463) is applied by k_nms
+    long slots = 0;
+    for (int i = 0; i < net->layer_num; i++)
+        if (net->layer_list[i].type == LAYER_TYPE_YOLO) slots += 3L * net->layer_list[i].w * net->layer_list[i].h;
+    if (slots > (1L << 24) || slots * batch > (1L << 28)) { ffgpu_set_error("executor: %ld candidate slots per frame x %d frames is too many", slots, batch); delete ex; return nullptr; }
+    ex->cand_cap = (int)std::max(slots, 1L);
+    ex->bbox_max = std::max(net->bbox_max, 1);
+    int cap_p2 = 1;
+    while (cap_p2 < ex->cand_cap) cap_p2 <<= 1;
+    const size_t ncs = (size_t)ex->cand_cap * (size_t)batch;
     bool ok = hipStreamCreateWithFlags(&ex->own_stream, hipStreamNonBlocking) == hipSuccess
            && hipStreamCreateWithFlags(&ex->side_stream, hipStreamNonBlocking) == hipSuccess
            && hipEventCreateWithFlags(&ex->ev_fork, hipEventDisableTiming) == hipSuccess
            && hipEventCreateWithFlags(&ex->ev_join, hipEventDisableTiming) == hipSuccess
-           && hipMalloc(&ex->d_cand, sizeof(BBOX) * FFGPU_MAX_CAND * (size_t)batch) == hipSuccess
-           && hipMalloc(&ex->d_cand_key, sizeof(int) * FFGPU_MAX_CAND * (size_t)batch) == hipSuccess
+           && hipMalloc(&ex->d_cand, sizeof(BBOX) * ncs) == hipSuccess
+           && hipMalloc(&ex->d_cand_key, sizeof(int) * ncs) == hipSuccess
+           && hipMalloc(&ex->d_full, sizeof(BBOX) * ncs) == hipSuccess
+           && hipMalloc(&ex->d_prm, sizeof(ExecParams)) == hipSuccess && hipMemset(ex->d_prm, 0, sizeof(ExecParams)) == hipSuccess
+           && (cap_p2 <= FFGPU_NMS_LDS_CAP || hipMalloc(&ex->d_nms_scratch, (size_t)13 * cap_p2 * batch) == hipSuccess)
            && hipMalloc(&ex->d_ncand, sizeof(int) * (size_t)batch) == hipSuccess && hipMemset(ex->d_ncand, 0, sizeof(int) * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_ringctr, sizeof(int)) == hipSuccess && hipMemset(ex->d_ringctr, 0, sizeof(int)) == hipSuccess
@@ -692,8 +792,9 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
         for (int c = 0; c < K; c++) {
             ffgpu_exec *ch = ffgpu_exec_create(net, batch / K, (flags & ~FFGPU_HOST_DETS) | FFGPU_INTERNAL_CHILD);
             if (!ch) { ffgpu_exec_destroy(ex); return nullptr; }
-            (void)hipFree(ch->d_dets);
+            (void)hipFree(ch->d_dets); (void)hipFree(ch->d_full);
             ch->d_dets = ex->d_dets + (size_t)c * (batch / K);
+            ch->d_full = ex->d_full + (size_t)c * (batch / K) * ex->cand_cap;
             ch->h_dets_dev = ex->h_dets_dev ? ex->h_dets_dev + (size_t)c * (batch / K) : nullptr;
             ex->child[c] = ch; ex->nchild = c + 1;
             ex->kernel_count += ch->kernel_count;
@@ -702,10 +803,11 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
                       hipEventCreateWithFlags(&ex->part_ev[c], hipEventDisableTiming) != hipSuccess)) {
                 ffgpu_set_error("split executor: stream / event creation failed"); ffgpu_exec_destroy(ex); return nullptr; }
         }
+        { std::lock_guard<std::mutex> lk(dev->mu); dev->execs.push_back(ex); }
         return ex;
     }
     if (plan(ex) != 0 || repack(ex, ex->own_stream) != 0 || hipStreamSynchronize(ex->own_stream) != hipSuccess) { ffgpu_exec_destroy(ex); return nullptr; }
-    dev->execs.push_back(ex);
+    { std::lock_guard<std::mutex> lk(dev->mu); dev->execs.push_back(ex); }
     return ex;
 }
 
@@ -722,12 +824,16 @@ extern "C" void ffgpu_exec_destroy(ffgpu_exec *ex)
         if (ex->part_stream[c]) (void)hipStreamDestroy(ex->part_stream[c]);
         if (ex->part_ev[c]) (void)hipEventDestroy(ex->part_ev[c]);
     }
-    if (ex->is_child) ex->d_dets = nullptr;                      // a slice of the parent's records
-    if (ex->dev) ex->dev->execs.erase(std::remove(ex->dev->execs.begin(), ex->dev->execs.end(), ex), ex->dev->execs.end());
-    for (auto &g : ex->graphs) (void)hipGraphExecDestroy(g.second);
+    if (ex->is_child) { ex->d_dets = nullptr; ex->d_full = nullptr; }      // slices of the parent's buffers
+    if (ex->dev) {
+        std::lock_guard<std::mutex> lk(ex->dev->mu);
+        ex->dev->execs.erase(std::remove(ex->dev->execs.begin(), ex->dev->execs.end(), ex), ex->dev->execs.end());
+    }
+    drop_graphs(ex);
     for (const Step &st : ex->steps) if (st.kind == S_TOCNHW) (void)hipFree(st.out);
     (void)hipFree(ex->arena); (void)hipFree(ex->d_input); (void)hipFree(ex->d_pack); (void)hipFree(ex->d_cand);
     (void)hipFree(ex->d_cand_key); (void)hipFree(ex->d_ncand); (void)hipFree(ex->d_dets);
+    (void)hipFree(ex->d_full); (void)hipFree(ex->d_prm); (void)hipFree(ex->d_nms_scratch);
     if (ex->h_dets) (void)hipHostFree(ex->h_dets);
     (void)hipFree(ex->d_ringctr);
     if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
@@ -750,7 +856,8 @@ extern "C" int ffgpu_exec_set_scale(ffgpu_exec *ex, int s1, int s2)
 
 extern "C" int ffgpu_exec_forward_dev(ffgpu_exec *ex, const float *d_frames, void *stream)
 {
-    if (!ex || !d_frames) { ffgpu_set_error("forward_dev: NULL argument"); return -1; }
+    if (!alive(ex, "forward_dev")) return -1;
+    if (!d_frames) { ffgpu_set_error("forward_dev: NULL argument"); return -1; }
     return forward_on(ex, d_frames, stream ? (hipStream_t)stream : ex->own_stream);
 }
 
@@ -763,7 +870,8 @@ static int ensure_input(ffgpu_exec *ex)
 
 extern "C" int ffgpu_exec_forward_host(ffgpu_exec *ex, const float *h_frames)
 {
-    if (!ex || !h_frames) { ffgpu_set_error("forward_host: NULL argument"); return -1; }
+    if (!alive(ex, "forward_host")) return -1;
+    if (!h_frames) { ffgpu_set_error("forward_host: NULL argument"); return -1; }
     if (ensure_input(ex)) return -1;
     const size_t bytes = sizeof(float) * (size_t)ex->N * ex->in_c * ex->in_h * ex->in_w;
     FFGPU_CHECK(hipMemcpyAsync(ex->d_input, h_frames, bytes, hipMemcpyHostToDevice, ex->own_stream));
@@ -775,7 +883,8 @@ extern "C" int ffgpu_exec_forward_host(ffgpu_exec *ex, const float *h_frames)
 extern "C" int ffgpu_exec_forward_bgr_dev(ffgpu_exec *ex, const unsigned char *d_bgr, int w, int h,
                                           const float mean[3], const float norm[3], void *stream)
 {
-    if (!ex || !d_bgr || w <= 0 || h <= 0 || ex->in_c != 3) { ffgpu_set_error("forward_bgr_dev: bad arguments"); return -1; }
+    if (!alive(ex, "forward_bgr_dev")) return -1;
+    if (!d_bgr || w <= 0 || h <= 0 || ex->in_c != 3) { ffgpu_set_error("forward_bgr_dev: bad arguments"); return -1; }
     if (ensure_input(ex)) return -1;
     hipStream_t s = stream ? (hipStream_t)stream : ex->own_stream;
     const int W = ex->in_w, H = ex->in_h;
@@ -799,8 +908,7 @@ extern "C" int ffgpu_exec_set_ring_strided(ffgpu_exec *ex, void *dev_ring, int s
 {
     if (!ex || (dev_ring && (slots < 1 || slot_records < ex->N))) { ffgpu_set_error("set_ring: bad arguments"); return -1; }
     FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
-    for (auto &g : ex->graphs) (void)hipGraphExecDestroy(g.second);      // the ring pointer is a kernel argument of the graphs
-    ex->graphs.clear();
+    drop_graphs(ex);                                            // the ring pointer is a kernel argument of the graphs
     ex->ring = (ffgpu_frame_dets *)dev_ring; ex->ring_slots = dev_ring ? slots : 0; ex->ring_stride = slot_records;
     FFGPU_CHECK(hipMemset(ex->d_ringctr, 0, sizeof(int)));
     for (int c = 0; c < ex->nchild; c++) {                      // each part writes its slice of every slot
@@ -827,33 +935,61 @@ extern "C" const ffgpu_frame_dets *ffgpu_exec_dets_host(ffgpu_exec *ex)
 extern "C" int ffgpu_exec_read_dets(ffgpu_exec *ex, ffgpu_frame_dets *host_out, int max_frames)
 {
     if (!ex || !host_out) { ffgpu_set_error("read_dets: NULL argument"); return -1; }
-    const int n = std::min(max_frames, ex->N);
+    const int n = std::max(0, std::min(max_frames, ex->N));
     FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
     if (ex->h_dets) memcpy(host_out, ex->h_dets, sizeof(ffgpu_frame_dets) * (size_t)n);
     else FFGPU_CHECK(hipMemcpy(host_out, ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)n, hipMemcpyDeviceToHost));
     return n;
 }
 
+extern "C" int ffgpu_exec_cand_capacity(const ffgpu_exec *ex) { return ex ? ex->cand_cap : 0; }
+extern "C" int ffgpu_exec_graph_captures(const ffgpu_exec *ex)
+{
+    if (!ex) return 0;
+    int n = ex->captures;
+    for (int c = 0; c < ex->nchild; c++) n += ex->child[c]->captures;
+    return n;
+}
+
+extern "C" int ffgpu_exec_read_boxes(ffgpu_exec *ex, int frame, BBOX *host_out, int cap)
+{
+    if (!ex || frame < 0 || frame >= ex->N || cap < 0 || (cap > 0 && !host_out)) { ffgpu_set_error("read_boxes: bad arguments"); return -1; }
+    FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
+    int nfull = 0;
+    FFGPU_CHECK(hipMemcpy(&nfull, &ex->d_dets[frame].nfull, sizeof(int), hipMemcpyDeviceToHost));
+    const int n = std::min(nfull, cap);
+    if (n > 0) FFGPU_CHECK(hipMemcpy(host_out, ex->d_full + (size_t)frame * ex->cand_cap, sizeof(BBOX) * (size_t)n, hipMemcpyDeviceToHost));
+    return nfull;
+}
+
 extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float *host_out, size_t cap_floats)
 {
-    if (!ex || !host_out || frame < 0 || frame >= ex->N) { ffgpu_set_error("read_layer: bad arguments"); return -1; }
+    if (!alive(ex, "read_layer")) return -1;
+    if (!host_out || frame < 0 || frame >= ex->N) { ffgpu_set_error("read_layer: bad arguments"); return -1; }
     if (ex->child[0]) return ffgpu_exec_read_layer(ex->child[frame / ex->child[0]->N], layer, frame % ex->child[0]->N, host_out, cap_floats);
     FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
     if (layer == -2) {                                            // candidates in reference emission order
         int cnt = 0;
         FFGPU_CHECK(hipMemcpy(&cnt, &ex->d_dets[frame].ncand, sizeof(int), hipMemcpyDeviceToHost));    // (k_nms has reset d_ncand)
-        cnt = std::min(cnt, FFGPU_MAX_CAND);
+        cnt = std::min(cnt, ex->cand_cap);
         if ((size_t)cnt * 6 > cap_floats) { ffgpu_set_error("read_layer: buffer too small"); return -1; }
         std::vector<BBOX> b(cnt);
         std::vector<int> k(cnt), idx(cnt);
         if (cnt) {
-            FFGPU_CHECK(hipMemcpy(b.data(), ex->d_cand + (size_t)frame * FFGPU_MAX_CAND, sizeof(BBOX) * cnt, hipMemcpyDeviceToHost));
-            FFGPU_CHECK(hipMemcpy(k.data(), ex->d_cand_key + (size_t)frame * FFGPU_MAX_CAND, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+            FFGPU_CHECK(hipMemcpy(b.data(), ex->d_cand + (size_t)frame * ex->cand_cap, sizeof(BBOX) * cnt, hipMemcpyDeviceToHost));
+            FFGPU_CHECK(hipMemcpy(k.data(), ex->d_cand_key + (size_t)frame * ex->cand_cap, sizeof(int) * cnt, hipMemcpyDeviceToHost));
         }
         for (int i = 0; i < cnt; i++) idx[i] = i;
         std::sort(idx.begin(), idx.end(), [&](int a, int c) { return k[a] < k[c]; });
         for (int i = 0; i < cnt; i++) memcpy(host_out + 6 * i, &b[idx[i]], sizeof(BBOX));
         return cnt;
+    }
+    if (layer == -1) {                                            // the network input as the first layer saw it (frame-major)
+        const size_t fl = (size_t)ex->in_c * ex->in_h * ex->in_w;
+        if (!ex->last_frames) { ffgpu_set_error("read_layer: no forward has run yet"); return -1; }
+        if (fl > cap_floats) { ffgpu_set_error("read_layer: buffer too small"); return -1; }
+        FFGPU_CHECK(hipMemcpy(host_out, ex->last_frames + (size_t)frame * fl, fl * sizeof(float), hipMemcpyDeviceToHost));
+        return (int)fl;
     }
     if (!(ex->flags & FFGPU_KEEP_ALL)) { ffgpu_set_error("read_layer needs an FFGPU_KEEP_ALL executor"); return -1; }
     if (layer < 0 || layer >= ex->net->layer_num || ex->canon[layer] < 0 || !ex->readable[layer]) {
@@ -871,9 +1007,11 @@ extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float
 
 extern "C" int ffgpu_exec_profile(ffgpu_exec *ex, const float *d_frames, float us_by_kind[LAYER_TYPE_TOTOAL])
 {
-    if (!ex || !d_frames || !us_by_kind) { ffgpu_set_error("profile: NULL argument"); return -1; }
+    if (!alive(ex, "profile")) return -1;
+    if (!d_frames || !us_by_kind) { ffgpu_set_error("profile: NULL argument"); return -1; }
     if (ex->child[0]) { ffgpu_set_error("profile: not available on a split executor"); return -1; }
     hipStream_t s = ex->own_stream;
+    if (push_params(ex, d_frames, s)) return -1;
     std::vector<hipEvent_t> ev(ex->steps.size() + 1);
     for (auto &e : ev) FFGPU_CHECK(hipEventCreate(&e));
     if (issue_all(ex, d_frames, s)) return -1;                    // warm
@@ -897,9 +1035,11 @@ extern "C" int ffgpu_exec_profile(ffgpu_exec *ex, const float *d_frames, float u
 
 extern "C" int ffgpu_exec_profile_steps(ffgpu_exec *ex, const float *d_frames, int *layer_of, float *us, int cap)
 {
-    if (!ex || !d_frames || !layer_of || !us) { ffgpu_set_error("profile_steps: NULL argument"); return -1; }
+    if (!alive(ex, "profile_steps")) return -1;
+    if (!d_frames || !layer_of || !us) { ffgpu_set_error("profile_steps: NULL argument"); return -1; }
     if (ex->child[0]) { ffgpu_set_error("profile_steps: not available on a split executor"); return -1; }
     hipStream_t s = ex->own_stream;
+    if (push_params(ex, d_frames, s)) return -1;
     const int n = (int)std::min<size_t>(ex->steps.size(), (size_t)cap);
     std::vector<hipEvent_t> ev(ex->steps.size() + 1);
     for (auto &e : ev) FFGPU_CHECK(hipEventCreate(&e));
@@ -952,12 +1092,25 @@ extern "C" void ffgpu_netdev_destroy(void *p)
 {
     ffgpu_netdev *dev = (ffgpu_netdev *)p;
     if (!dev) return;
-    if (dev->exec1) ffgpu_exec_destroy(dev->exec1);
+    if (dev->exec1) { ffgpu_exec_destroy(dev->exec1); dev->exec1 = nullptr; }
+    // executors the caller still holds outlive the net as orphans: their steps point into d_weights and the layer table,
+    // so they wait for their streams here and from now on refuse to run (alive()); ffgpu_exec_destroy still frees them
+    std::vector<ffgpu_exec *> left;
+    { std::lock_guard<std::mutex> lk(dev->mu); left.swap(dev->execs); }
+    for (ffgpu_exec *ex : left) {
+        if (ex->last_stream) (void)hipStreamSynchronize(ex->last_stream);
+        ex->dev = nullptr; ex->net = nullptr;
+    }
     (void)hipFree(dev->d_weights);
     delete dev;
 }
 
-extern "C" int ffgpu_netdev_forward1(NET *net, void *p)
+// net_forward (ffcnn.c:476-520) for the one frame in layer_list[0].data: H2D, the batch-1 executor, boxes back into
+// net->bbox_list -- ALL of them, up to net->bbox_max like the reference (the fixed-size record holds the first
+// FFGPU_MAX_DET; the rest comes from the executor's full list).  profile != 0 (FFCNN_PROFILE=1, the counterpart of
+// ENABLE_NET_PROFILE, ffcnn.c:33,494-510): the forward runs launch by launch between HIP events and the device time of
+// every layer kind is added to net->timeused[] (whole milliseconds of the accumulated time, as the reference keeps them).
+extern "C" int ffgpu_netdev_forward1(NET *net, void *p, int profile)
 {
     ffgpu_netdev *dev = (ffgpu_netdev *)p;
     if (!dev->exec1) {
@@ -967,12 +1120,29 @@ extern "C" int ffgpu_netdev_forward1(NET *net, void *p)
     ffgpu_exec *ex = dev->exec1;
     ex->s1 = net->s1 ? net->s1 : 1;
     ex->s2 = net->s2 ? net->s2 : 1;
-    if (ffgpu_exec_forward_host(ex, net->layer_list[0].data)) return -1;
+    ex->bbox_max = std::max(net->bbox_max, 1);
+    if (profile) {
+        if (ensure_input(ex)) return -1;
+        FFGPU_CHECK(hipMemcpy(ex->d_input, net->layer_list[0].data, sizeof(float) * (size_t)ex->in_c * ex->in_h * ex->in_w, hipMemcpyHostToDevice));
+        float us[LAYER_TYPE_TOTOAL];
+        if (ffgpu_exec_profile(ex, ex->d_input, us)) return -1;
+        for (int k = 0; k < LAYER_TYPE_TOTOAL; k++) { dev->us_acc[k] += us[k]; net->timeused[k] = (int)(dev->us_acc[k] / 1000.0 + 0.5); }
+    } else if (ffgpu_exec_forward_host(ex, net->layer_list[0].data)) return -1;
     static thread_local ffgpu_frame_dets rec;
     if (ffgpu_exec_read_dets(ex, &rec, 1) != 1) return -1;
-    net->bbox_num = std::min(rec.count, net->bbox_max);
-    memcpy(net->bbox_list, rec.box, sizeof(BBOX) * FFGPU_MAX_DET);
-    if (rec.overflow) fprintf(stderr, "ffcnn: more than %d candidates or %d boxes in one frame; extras dropped\n", FFGPU_MAX_CAND, FFGPU_MAX_DET);
+    const ffcnn_ext *ext = ffcnn_ext_of(net);
+    const int nb = std::max(0, std::min(rec.nfull, std::min(net->bbox_max, ext ? ext->box_cap : FFGPU_MAX_DET)));
+    if (nb <= FFGPU_MAX_DET) memcpy(net->bbox_list, rec.box, sizeof(BBOX) * (size_t)nb);
+    else if (ffgpu_exec_read_boxes(ex, 0, net->bbox_list, nb) < 0) return -1;
+    net->bbox_num = nb;
+    return 0;
+}
+
+extern "C" int ffgpu_netdev_profile_us(void *p, double us_by_kind[LAYER_TYPE_TOTOAL])
+{
+    ffgpu_netdev *dev = (ffgpu_netdev *)p;
+    if (!dev) return -1;
+    for (int k = 0; k < LAYER_TYPE_TOTOAL; k++) us_by_kind[k] = dev->us_acc[k];
     return 0;
 }
 
@@ -989,6 +1159,7 @@ extern "C" int ffgpu_net_weights_commit(NET *net, void *stream)
 {
     ffgpu_netdev *dev = netdev_of(net);
     if (!dev) return -1;
+    std::lock_guard<std::mutex> lk(dev->mu);
     for (ffgpu_exec *ex : dev->execs)           // fused blocks keep their constants in a packed LDS image
         if (repack(ex, stream ? (hipStream_t)stream : ex->own_stream)) return -1;
     if (!stream) for (ffgpu_exec *ex : dev->execs) FFGPU_CHECK(hipStreamSynchronize(ex->own_stream));

@@ -20,6 +20,7 @@ typedef struct {
     int      profile;          /* FFCNN_PROFILE=1: fill NET.timeused            */
     void    *dev;              /* ffgpu_netdev* (device weights + executors)    */
     BBOX    *own_boxes;        /* bbox_list storage (NOT aliased onto the input)*/
+    int      box_cap;          /* boxes own_boxes has room for (= bbox_max at load) */
 } ffcnn_ext;
 
 static inline ffcnn_ext *ffcnn_ext_of(NET *net)
@@ -31,7 +32,9 @@ static inline ffcnn_ext *ffcnn_ext_of(NET *net)
 /* implemented in ffgpu_exec.hip */
 void *ffgpu_netdev_create(NET *net);              /* uploads weight_buf; NULL on failure */
 void  ffgpu_netdev_destroy(void *dev);
-int   ffgpu_netdev_forward1(NET *net, void *dev); /* one frame from layer_list[0].data -> bbox_list */
+int   ffgpu_netdev_forward1(NET *net, void *dev, int profile); /* one frame from layer_list[0].data -> bbox_list;  */
+                                                  /* profile: per-kind device time added to net->timeused  */
+int   ffgpu_netdev_profile_us(void *dev, double us_by_kind[LAYER_TYPE_TOTOAL]);   /* the same, in microseconds */
 void  ffgpu_set_error(const char *fmt, ...);
 
 #ifdef __cplusplus

@@ -36,6 +36,7 @@ __global__ void k_conv_generic(ConvDesc d)
     const int gic = d.ic / d.groups, goc = d.oc / d.groups;
     const int k4 = (d.fs * d.fs * gic + 3) & ~3, rl = k4 + 4;
     const bool v6dw5 = (d.flags & FFGPU_COMPAT_V6) && d.pad == 2 && d.fs == 5 && d.stride == 1 && gic == 1;
+    const float *in0 = d.in_ind ? *d.in_ind : d.in;                  // executor parameter block (one graph for every input buffer)
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int x = (int)(idx % d.ow);
         long t = idx / d.ow;
@@ -44,7 +45,7 @@ __global__ void k_conv_generic(ConvDesc d)
         const int o = (int)(t / d.N);
         const int g = o / goc;
         const float *w = d.filt + (long)o * rl;
-        const float *src = d.in + (long)g * gic * d.in_cs + (long)n * d.in_ns;
+        const float *src = in0 + (long)g * gic * d.in_cs + (long)n * d.in_ns;
         float acc = 0.f;
         for (int ci = 0; ci < gic; ci++) {
             const float *pl = src + (long)ci * d.in_cs;
@@ -233,7 +234,7 @@ __global__ void k_input_bgr(const unsigned char *bgr, float *out, int N, int w, 
 // evaluated in double and narrowed exactly where the reference does, and FMA
 // contraction is off so the confidence/box arithmetic rounds like the C code.
 // ring_ctr (one head of a forward only, may be NULL): this forward's number for the record ring -- counted here, consumed by k_nms
-__global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, int *ring_ctr)
+__global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, int cap, int *ring_ctr)
 {
 #pragma clang fp contract(off)
     if (ring_ctr && blockIdx.x == 0 && threadIdx.x == 0) *ring_ctr += 1;
@@ -287,62 +288,85 @@ __global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *
     const float bw = (float)exp((double)tw) * hd.anchors[k][0] * hd.scale_xy;
     const float bh = (float)exp((double)th) * hd.anchors[k][1] * hd.scale_xy;
     const int slot = atomicAdd(&ncand[n], 1);
-    if (slot >= FFGPU_MAX_CAND) return;
+    if (slot >= cap) return;                 // cannot happen: cap = 3 * cells over all heads (one slot per anchor)
     BBOX b;
     b.type = best; b.score = conf;
     b.x1 = cx - bw * 0.5f; b.y1 = cy - bh * 0.5f;
     b.x2 = cx + bw * 0.5f; b.y2 = cy + bh * 0.5f;
-    cand[(long)n * FFGPU_MAX_CAND + slot] = b;
-    cand_key[(long)n * FFGPU_MAX_CAND + slot] = hd.key_base + cell * 3 + k;   // reference emission order
+    cand[(long)n * cap + slot] = b;
+    cand_key[(long)n * cap + slot] = hd.key_base + cell * 3 + k;   // reference emission order
 }
 
 // NMS (ffcnn.c:298-335): one workgroup per frame.  Candidates are ordered by
-// (score desc, emission key asc) with a bitonic sort in LDS -- the key makes the
+// (score desc, emission key asc) with a bitonic sort -- the key makes the
 // order total where qsort's is unspecified -- then suppressed greedily per class
 // with inter/min(area) (or IoU) > thresh, compacted and rescaled by s1/s2.
+// Capacity: every anchor of every cell has a candidate slot (cap per frame), so nothing is dropped before the sort; the
+// reference's own limit -- it stops appending at net->bbox_max in EMISSION order (ffcnn.c:463) -- is reproduced by a
+// first sort on the emission key when a frame has more candidates than that (never with the default bbox_max = 51 200).
+// Work arrays (score, key, index, alive: 13 bytes per slot of the next power of two) live in LDS up to
+// FFGPU_NMS_LDS_CAP slots and in a global scratch buffer beyond (GLB).
 // dets_host (may be NULL): pinned host mirror of the records, written by the same threads (FFGPU_HOST_DETS) so a
 // single-GPU consumer needs no device-to-host copy after the forward
 // ring (may be NULL): caller-owned device ring of ring_slots x N records; forward number *ring_ctr (counted by k_clear at
 // the start of the forward) goes to slot (*ring_ctr - 1) % ring_slots -- the multi-GPU job gathers whole groups of slots
-__global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_key, int *ncand,
+// full (may be NULL): ALL survivors of the frame in score order (cap slots per frame); the fixed-size record holds the first
+// FFGPU_MAX_DET of them and their total number in `nfull`
+template <bool GLB>
+__global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, int cap_p2, int bbox_max,
+                                             BBOX *full, unsigned char *scratch,
                                              ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, ffgpu_frame_dets *ring, int ring_slots,
-                                             int ring_stride, const int *ring_ctr, float thresh, int use_min, int s1, int s2)
+                                             int ring_stride, const int *ring_ctr, float thresh, int use_min, const ExecParams *prm)
 {
 #pragma clang fp contract(off)
-    __shared__ float s_score[FFGPU_MAX_CAND];
-    __shared__ int   s_key[FFGPU_MAX_CAND];
-    __shared__ short s_idx[FFGPU_MAX_CAND];
-    __shared__ unsigned char s_alive[FFGPU_MAX_CAND];
+    extern __shared__ __attribute__((aligned(16))) unsigned char nms_lds[];
+    unsigned char *wb = GLB ? scratch + (size_t)blockIdx.x * cap_p2 * 13 : nms_lds;
+    float *s_score = reinterpret_cast<float *>(wb);
+    int   *s_key = reinterpret_cast<int *>(wb + (size_t)4 * cap_p2);
+    int   *s_idx = reinterpret_cast<int *>(wb + (size_t)8 * cap_p2);
+    unsigned char *s_alive = wb + (size_t)12 * cap_p2;
     const int n = blockIdx.x, tid = threadIdx.x;
+    const int s1 = prm->s1, s2 = prm->s2;
     const int total = ncand[n];
-    const int m = min(total, FFGPU_MAX_CAND);
-    const BBOX *c = cand + (long)n * FFGPU_MAX_CAND;
+    int m = min(total, cap);
+    const BBOX *c = cand + (long)n * cap;
     ffgpu_frame_dets *out = dets + n;
     int pow2 = 1;
     while (pow2 < m) pow2 <<= 1;
     for (int i = tid; i < pow2; i += blockDim.x) {
         s_score[i] = i < m ? c[i].score : -1.f;
-        s_key[i] = i < m ? cand_key[(long)n * FFGPU_MAX_CAND + i] : 0x7fffffff;
-        s_idx[i] = (short)i;
+        s_key[i] = i < m ? cand_key[(long)n * cap + i] : 0x7fffffff;
+        s_idx[i] = i;
     }
     __syncthreads();
-    for (int k = 2; k <= pow2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < pow2; i += blockDim.x) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const bool up = (i & k) == 0;
-                    // "a precedes b": higher score first, then lower key
-                    const bool a_first = s_score[i] > s_score[l] || (s_score[i] == s_score[l] && s_key[i] < s_key[l]);
-                    if (a_first != up) {
-                        const float ts = s_score[i]; s_score[i] = s_score[l]; s_score[l] = ts;
-                        const int tk = s_key[i]; s_key[i] = s_key[l]; s_key[l] = tk;
-                        const short ti = s_idx[i]; s_idx[i] = s_idx[l]; s_idx[l] = ti;
+    // BYKEY: ascending emission key only (the pass that reproduces the reference's truncation); else (score desc, key asc)
+    auto sort = [&](bool bykey) {
+        for (int k = 2; k <= pow2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < pow2; i += blockDim.x) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const bool up = (i & k) == 0;
+                        // "a precedes b"
+                        const bool a_first = bykey ? s_key[i] < s_key[l]
+                                                   : (s_score[i] > s_score[l] || (s_score[i] == s_score[l] && s_key[i] < s_key[l]));
+                        if (a_first != up) {
+                            const float ts = s_score[i]; s_score[i] = s_score[l]; s_score[l] = ts;
+                            const int tk = s_key[i]; s_key[i] = s_key[l]; s_key[l] = tk;
+                            const int ti = s_idx[i]; s_idx[i] = s_idx[l]; s_idx[l] = ti;
+                        }
                     }
                 }
+                __syncthreads();
             }
-            __syncthreads();
-        }
+    };
+    if (m > bbox_max) {                                   // uniform; keep the first bbox_max in emission order (ffcnn.c:463)
+        sort(true);
+        for (int i = bbox_max + tid; i < pow2; i += blockDim.x) { s_score[i] = -1.f; s_key[i] = 0x7fffffff; }
+        m = bbox_max;
+        __syncthreads();
+    }
+    sort(false);
     for (int i = tid; i < m; i += blockDim.x) s_alive[i] = 1;
     __syncthreads();
     for (int a = 0; a < m; a++) {
@@ -363,46 +387,53 @@ __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_k
         }
         __syncthreads();
     }
-    // survivors in score order -> record slots (one thread walks the list, every thread writes one slot)
-    __shared__ short s_keep[FFGPU_MAX_DET];
-    __shared__ int s_nkeep, s_clipped;
+    // survivors in score order: one thread walks the list (the key array has served its purpose and becomes the list),
+    // every thread then writes slots
+    __shared__ int s_nkeep;
     if (tid == 0) {
-        int keep = 0, clipped = 0;
-        for (int i = 0; i < m; i++) {
-            if (!s_alive[i]) continue;
-            if (keep == FFGPU_MAX_DET) { clipped = 1; break; }
-            s_keep[keep++] = s_idx[i];
-        }
-        s_nkeep = keep; s_clipped = clipped;
+        int keep = 0;
+        for (int i = 0; i < m; i++) if (s_alive[i]) s_key[keep++] = s_idx[i];
+        s_nkeep = keep;
     }
     __syncthreads();
+    const int nfull = s_nkeep, nrec = min(nfull, FFGPU_MAX_DET);
+    auto scaled = [&](int i) {
+        const BBOX b = c[s_key[i]];
+        BBOX r;
+        r.type = b.type; r.score = b.score;
+        r.x1 = b.x1 * s1 / s2; r.y1 = b.y1 * s1 / s2;
+        r.x2 = b.x2 * s1 / s2; r.y2 = b.y2 * s1 / s2;
+        return r;
+    };
+    if (full) for (int i = tid; i < nfull; i += blockDim.x) full[(long)n * cap + i] = scaled(i);
     ffgpu_frame_dets *outs[3] = { out, dets_host ? dets_host + n : nullptr, nullptr };
     if (ring) outs[2] = ring + (size_t)((unsigned)(*ring_ctr - 1) % (unsigned)ring_slots) * ring_stride + n;
     // slots at or beyond both the previous and the new count are zero already in the record and its host mirror (both
     // start zeroed and are only ever written here): the mirror, which sits across PCIe, is touched only where it
     // changes.  A ring slot last held some older forward's record, so it is written in full.
-    const int nwrite = max(s_nkeep, min(max(out->count, 0), FFGPU_MAX_DET));
+    const int nwrite = max(nrec, min(max(out->count, 0), FFGPU_MAX_DET));
     __syncthreads();                                               // every thread has read the old count
     for (int i = tid; i < FFGPU_MAX_DET; i += blockDim.x) {
         BBOX r = { 0, 0.f, 0.f, 0.f, 0.f, 0.f };                   // reference zeroes the tail (ffcnn.c:333)
-        if (i < s_nkeep) {
-            const BBOX b = c[s_keep[i]];
-            r.type = b.type; r.score = b.score;
-            r.x1 = b.x1 * s1 / s2; r.y1 = b.y1 * s1 / s2;
-            r.x2 = b.x2 * s1 / s2; r.y2 = b.y2 * s1 / s2;
-        }
+        if (i < nrec) r = scaled(i);
         if (i < nwrite) { outs[0]->box[i] = r; if (outs[1]) outs[1]->box[i] = r; }
         if (outs[2]) outs[2]->box[i] = r;
     }
     if (tid == 0) {
         for (int k = 0; k < 3; k++) if (outs[k]) {
-            outs[k]->count = s_nkeep;
+            outs[k]->count = nrec;
             outs[k]->ncand = total;
-            outs[k]->overflow = (total > FFGPU_MAX_CAND) | s_clipped;
-            outs[k]->reserved = 0;
+            outs[k]->overflow = (total > bbox_max ? 1 : 0) | (nfull > FFGPU_MAX_DET ? 4 : 0);
+            outs[k]->nfull = nfull;
         }
         ncand[n] = 0;                                              // the next forward's heads start counting from zero (no clear launch)
     }
+}
+
+// the executor's parameter block (ExecParams): rewritten in stream order in front of a graph launch
+__global__ void k_set_params(ExecParams *prm, const float *frames, int s1, int s2)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { prm->frames = frames; prm->s1 = s1; prm->s2 = s2; }
 }
 
 // start of a forward: no candidates yet; one more forward for the record ring
@@ -488,20 +519,44 @@ int ffgpu_launch_input_bgr(const unsigned char *bgr, float *out, int N, int w, i
     return 0;
 }
 
-int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, int *ring_ctr, hipStream_t s)
+int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand, int *cand_key, int *ncand, int cap, int *ring_ctr, hipStream_t s)
 {
     const long total = (long)N * 3 * hd.w * hd.h;
-    hipLaunchKernelGGL(k_yolo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hd, N, netw, neth, cand, cand_key, ncand, ring_ctr);
+    hipLaunchKernelGGL(k_yolo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hd, N, netw, neth, cand, cand_key, ncand, cap, ring_ctr);
     LAUNCH_OK("yolo");
     return 0;
 }
 
-int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
+int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, int bbox_max, BBOX *full, void *scratch,
+                     ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
                      ffgpu_frame_dets *ring, int ring_slots, int ring_stride, const int *ring_ctr, int N,
-                     float thresh, int use_min, int s1, int s2, hipStream_t s)
+                     float thresh, int use_min, const ExecParams *prm, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_nms, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, dets, dets_host, ring, ring_slots, ring_stride, ring_ctr, thresh, use_min, s1, s2);
+    int p2 = 1;
+    while (p2 < cap) p2 <<= 1;
+    if (p2 > FFGPU_NMS_LDS_CAP) {
+        if (!scratch) { ffgpu_set_error("nms: %d candidate slots per frame need the global scratch buffer", cap); return -1; }
+        hipLaunchKernelGGL(k_nms<true>, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, cap, p2, bbox_max, full, (unsigned char *)scratch,
+                           dets, dets_host, ring, ring_slots, ring_stride, ring_ctr, thresh, use_min, prm);
+    } else {
+        const size_t lds = (size_t)13 * p2;
+        static bool raised = false;                                // > 64 KB of dynamic LDS needs the attribute (once per process)
+        if (lds > 64 * 1024 && !raised) {
+            if (hipFuncSetAttribute((const void *)k_nms<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 13 * FFGPU_NMS_LDS_CAP) != hipSuccess) {
+                ffgpu_set_error("nms: cannot raise the dynamic LDS limit"); return -1; }
+            raised = true;
+        }
+        hipLaunchKernelGGL(k_nms<false>, dim3(N), dim3(256), lds, s, cand, cand_key, ncand, cap, p2, bbox_max, full, nullptr,
+                           dets, dets_host, ring, ring_slots, ring_stride, ring_ctr, thresh, use_min, prm);
+    }
     LAUNCH_OK("nms");
+    return 0;
+}
+
+int ffgpu_launch_set_params(ExecParams *d_prm, const float *frames, int s1, int s2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, s, d_prm, frames, s1, s2);
+    LAUNCH_OK("set_params");
     return 0;
 }
 
@@ -510,82 +565,6 @@ int ffgpu_launch_clear(int *ncand, int N, int *ring_ctr, hipStream_t s)
     hipLaunchKernelGGL(k_clear, dim3((N + 255) / 256), dim3(256), 0, s, ncand, N, ring_ctr);
     LAUNCH_OK("clear");
     return 0;
-}
-
-// ---------------------------------------------------------------------------
-// HBM stream calibration (ffgpu_membench)
-typedef float mb4 __attribute__((ext_vector_type(4)));
-template <int MODE>
-__global__ void __launch_bounds__(256) k_membench(mb4 *dst, const mb4 *src, long n4)
-{
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, gsz = (long)gridDim.x * blockDim.x;
-    if (MODE == 0) for (long i = gid; i < n4; i += gsz) dst[i] = src[i];
-    if (MODE == 1) for (long i = gid; i < n4; i += gsz) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
-    if (MODE == 2) {
-        mb4 a = { 0.f, 0.f, 0.f, 0.f };
-        for (long i = gid; i < n4; i += gsz) a += src[i];
-        if (a.x + a.y + a.z + a.w == 12345.678f) dst[gid] = a;      // keep the loads alive
-    }
-    if (MODE == 3) { const mb4 v = { 1.f, 2.f, 3.f, 4.f }; for (long i = gid; i < n4; i += gsz) dst[i] = v; }
-    if (MODE == 5 || MODE == 6 || MODE == 7) {
-        // MODE 5: every WAVE owns one contiguous span and walks it with 4 x 1 KiB pieces in flight
-        // MODE 6: every BLOCK owns one contiguous span; its waves interleave at 1 KiB granularity
-        // MODE 7: as 5 with non-temporal loads and stores
-        const int lane = threadIdx.x & 63;
-        const long nw = (long)gridDim.x * (blockDim.x >> 6), w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        long b, e, step;
-        if (MODE == 6) {
-            const long per = ((n4 + gridDim.x - 1) / gridDim.x + 255) & ~255L;
-            b = blockIdx.x * per + (threadIdx.x >> 6) * 64; e = min(b - (threadIdx.x >> 6) * 64 + per, n4); step = blockDim.x;
-        } else {
-            const long per = ((n4 + nw - 1) / nw + 63) & ~63L;
-            b = w * per; e = min(b + per, n4); step = 64;
-        }
-        long i = b + lane;
-        for (; i + 3 * step < e; i += 4 * step) {
-            mb4 a0, a1, a2, a3;
-            if (MODE == 7) { a0 = __builtin_nontemporal_load(src + i); a1 = __builtin_nontemporal_load(src + i + step);
-                             a2 = __builtin_nontemporal_load(src + i + 2 * step); a3 = __builtin_nontemporal_load(src + i + 3 * step); }
-            else { a0 = src[i]; a1 = src[i + step]; a2 = src[i + 2 * step]; a3 = src[i + 3 * step]; }
-            if (MODE == 7) { __builtin_nontemporal_store(a0, dst + i); __builtin_nontemporal_store(a1, dst + i + step);
-                             __builtin_nontemporal_store(a2, dst + i + 2 * step); __builtin_nontemporal_store(a3, dst + i + 3 * step); }
-            else { dst[i] = a0; dst[i + step] = a1; dst[i + 2 * step] = a2; dst[i + 3 * step] = a3; }
-        }
-        for (; i < e; i += step) dst[i] = src[i];
-    }
-    if (MODE == 4) {
-        long i = gid;
-        for (; i + 3 * gsz < n4; i += 4 * gsz) {
-            const mb4 a = src[i], b = src[i + gsz], c = src[i + 2 * gsz], d = src[i + 3 * gsz];
-            dst[i] = a; dst[i + gsz] = b; dst[i + 2 * gsz] = c; dst[i + 3 * gsz] = d;
-        }
-        for (; i < n4; i += gsz) dst[i] = src[i];
-    }
-}
-
-// ---------------------------------------------------------------------------
-// pipe probe (diagnostics): how the matrix cores and the vector ALU of a SIMD share time.  Every wave runs `iters` trips
-// of [NM independent v_mfma_f32_16x16x4_f32] + [NV independent v_fma_f32]; blocks * 4 waves are launched so the
-// caller controls waves per SIMD.  Result: microseconds per launch.
-template <int NM, int NV>
-__global__ void __launch_bounds__(256) k_pipe_probe(float *out, int iters)
-{
-    typedef float pv4 __attribute__((ext_vector_type(4)));
-    pv4 acc[16];
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) { acc[i] = (pv4){ 0.f, 0.f, 0.f, 0.f }; v[i] = (float)threadIdx.x + i; }
-    const float a = 1.0f + threadIdx.x * 1e-6f, b = 0.999f;
-    for (int it = 0; it < iters; it++) {
-#pragma unroll
-        for (int i = 0; i < NM; i++) acc[i & 15] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i & 15], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NV; i++) v[i & 15] = fmaf(v[i & 15], b, a);
-    }
-    float r = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; i++) r += acc[i].x + acc[i].y + acc[i].z + acc[i].w + v[i];
-    if (r == 12345.678f) out[threadIdx.x] = r;                  // keep the work alive
 }
 
 // ---- compact form of the detection records for the multi-GPU gather: a step's `batch` fixed-size records (3088 bytes
@@ -633,119 +612,3 @@ extern "C" int ffgpu_pack_records(const void *d_records, int nslots, long slot_s
     return 0;
 }
 
-// ---- does vector-ALU work hide in the shadow of an MFMA?  Hand-placed instruction streams (inline asm, nothing for the
-// compiler to repack or reorder): MODE 0: 16 x MFMA; 1: 16 x (MFMA, NS plain v_fma_f32); 2: 16 x (MFMA, NS/2 v_pk_fma_f32);
-// 3: 16 x NS v_fma_f32 alone; 4: 16 x NS/2 v_pk_fma_f32 alone.  All operands independent of each other.
-template <int MODE, int NS>
-__global__ void __launch_bounds__(256) k_pipe_probe2(float *out, int iters)
-{
-    typedef float pv4 __attribute__((ext_vector_type(4)));
-    typedef float pv2 __attribute__((ext_vector_type(2)));
-    pv4 acc[16];
-    float v[8];
-    pv2 w[4];
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = (pv4){ 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = (float)threadIdx.x + i;
-#pragma unroll
-    for (int i = 0; i < 4; i++) w[i] = (pv2){ (float)threadIdx.x + i, 1.f };
-    const float a = 1.0f + threadIdx.x * 1e-6f, b = 0.999f;
-    const pv2 b2 = { b, b }, a2 = { a, a };
-    for (int it = 0; it < iters; it++) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            if (MODE <= 2) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
-            if (MODE == 1 || MODE == 3) {
-#pragma unroll
-                for (int j = 0; j < NS; j++) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[j & 7]) : "v"(b), "v"(a));
-            }
-            if (MODE == 2 || MODE == 4) {
-#pragma unroll
-                for (int j = 0; j < NS / 2; j++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(w[j & 3]) : "v"(b2), "v"(a2));
-            }
-        }
-    }
-    float r = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; i++) r += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r += v[i];
-#pragma unroll
-    for (int i = 0; i < 4; i++) r += w[i].x + w[i].y;
-    if (r == 12345.678f) out[threadIdx.x] = r;
-}
-
-extern "C" float ffgpu_pipe_probe2(int mode, int ns, int blocks, int iters, void *stream)
-{
-    hipStream_t s = (hipStream_t)stream;
-    static float *d_out = nullptr;
-    if (!d_out && hipMalloc(&d_out, 256 * sizeof(float)) != hipSuccess) return -1.f;
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
-    for (int rep = 0; rep < 3; rep++) {
-        if (rep == 1) (void)hipEventRecord(e0, s);
-#define PP2(M, N) if (mode == M && ns == N) hipLaunchKernelGGL((k_pipe_probe2<M, N>), dim3(blocks), dim3(256), 0, s, d_out, iters); else
-        PP2(0, 0) PP2(1, 2) PP2(1, 4) PP2(1, 6) PP2(1, 8) PP2(2, 2) PP2(2, 4) PP2(2, 6) PP2(2, 8) PP2(3, 4) PP2(3, 8) PP2(4, 4) PP2(4, 8)
-        { ffgpu_set_error("pipe_probe2: unsupported mix"); return -1.f; }
-#undef PP2
-    }
-    (void)hipEventRecord(e1, s);
-    if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return ms * 1000.f / 2;
-}
-
-extern "C" float ffgpu_pipe_probe(int n_mfma, int n_valu, int blocks, int iters, void *stream)
-{
-    hipStream_t s = (hipStream_t)stream;
-    static float *d_out = nullptr;
-    if (!d_out && hipMalloc(&d_out, 256 * sizeof(float)) != hipSuccess) return -1.f;
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
-    for (int rep = 0; rep < 3; rep++) {
-        if (rep == 1) (void)hipEventRecord(e0, s);
-        if (n_mfma == 16 && n_valu == 0)       hipLaunchKernelGGL((k_pipe_probe<16, 0>), dim3(blocks), dim3(256), 0, s, d_out, iters);
-        else if (n_mfma == 0 && n_valu == 64)  hipLaunchKernelGGL((k_pipe_probe<0, 64>), dim3(blocks), dim3(256), 0, s, d_out, iters);
-        else if (n_mfma == 16 && n_valu == 64) hipLaunchKernelGGL((k_pipe_probe<16, 64>), dim3(blocks), dim3(256), 0, s, d_out, iters);
-        else if (n_mfma == 16 && n_valu == 128) hipLaunchKernelGGL((k_pipe_probe<16, 128>), dim3(blocks), dim3(256), 0, s, d_out, iters);
-        else if (n_mfma == 0 && n_valu == 128) hipLaunchKernelGGL((k_pipe_probe<0, 128>), dim3(blocks), dim3(256), 0, s, d_out, iters);
-        else { ffgpu_set_error("pipe_probe: unsupported mix"); return -1.f; }
-    }
-    (void)hipEventRecord(e1, s);
-    if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return ms * 1000.f / 2;
-}
-
-extern "C" float ffgpu_membench(void *d_dst, const void *d_src, size_t bytes, int mode, int blocks, int iters, void *stream)
-{
-    hipStream_t s = (hipStream_t)stream;
-    const long n4 = (long)(bytes / 16);
-    if (!d_dst || !d_src || n4 < 1 || blocks < 1 || iters < 1) { ffgpu_set_error("membench: bad arguments"); return -1.f; }
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
-    for (int it = 0; it < iters + 2; it++) {
-        if (it == 2) (void)hipEventRecord(e0, s);
-        switch (mode) {
-        case 0: hipLaunchKernelGGL(k_membench<0>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
-        case 1: hipLaunchKernelGGL(k_membench<1>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
-        case 2: hipLaunchKernelGGL(k_membench<2>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
-        case 3: hipLaunchKernelGGL(k_membench<3>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
-        case 5: hipLaunchKernelGGL(k_membench<5>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
-        case 6: hipLaunchKernelGGL(k_membench<6>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
-        case 7: hipLaunchKernelGGL(k_membench<7>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
-        default: hipLaunchKernelGGL(k_membench<4>, dim3(blocks), dim3(256), 0, s, (mb4 *)d_dst, (const mb4 *)d_src, n4); break;
-        }
-    }
-    (void)hipEventRecord(e1, s);
-    if (hipEventSynchronize(e1) != hipSuccess) { ffgpu_set_error("membench: %s", hipGetErrorString(hipGetLastError())); return -1.f; }
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return ms * 1000.f / iters;
-}

@@ -27,16 +27,22 @@
 extern "C" {
 #endif
 
-#define FFGPU_MAX_DET   128   /* final boxes kept per frame (reference: bbox_max, ffcnn.c:243) */
-#define FFGPU_MAX_CAND  1024  /* pre-NMS candidates kept per frame                            */
+#define FFGPU_MAX_DET   128   /* boxes per frame in the fixed-size RECORD (the gather unit); a frame with more keeps   */
+                              /* all of them in the executor's full list: ffgpu_exec_read_boxes                        */
+
+/* Candidate capacity: the reference appends candidates to a buffer of net->bbox_max = 51 200 entries (ffcnn.c:243,463).
+ * Here every anchor of every head cell owns a slot (3 * cells summed over the heads: 1 500 per frame at 320x320), so the
+ * decode never drops one; if a frame ever has more than net->bbox_max candidates, the FIRST bbox_max in the reference's
+ * emission order go into NMS, as in the reference.  ffgpu_exec_cand_capacity() returns the slots per frame. */
 
 /* Per-frame detection record as it lies in device (and gathered host) memory.
  * This is the unit the multi-GPU gather moves: fixed size, 16 + 128*24 bytes. */
 typedef struct {
-    int  count;               /* boxes valid in box[] (post-NMS, source-image coords)  */
-    int  ncand;               /* candidates that passed ignore_thresh before NMS       */
-    int  overflow;            /* nonzero if ncand > FFGPU_MAX_CAND or count clipped    */
-    int  reserved;
+    int  count;               /* boxes valid in box[] (post-NMS, source-image coords): min(nfull, FFGPU_MAX_DET)     */
+    int  ncand;               /* candidates that passed ignore_thresh before NMS                                      */
+    int  overflow;            /* bit 0: ncand > bbox_max (truncated like the reference); bit 2: nfull > FFGPU_MAX_DET  */
+                              /* (bit 1 is set by ffgpu_pack_records on frames that lost boxes to its cap)             */
+    int  nfull;               /* boxes that survived NMS (all of them are in the executor's full list)                 */
     BBOX box[FFGPU_MAX_DET];
 } ffgpu_frame_dets;
 
@@ -86,7 +92,10 @@ int ffgpu_exec_set_scale(ffgpu_exec *ex, int s1, int s2);
 
 /* d_frames: device pointer, batch x C x H x W fp32 (frame-major).  Enqueues the
  * whole net + YOLO decode + NMS on `stream` (hipStream_t; NULL = the executor's
- * own stream) and returns without synchronising. */
+ * own stream) and returns without synchronising.  The executor replays ONE HIP
+ * graph whatever buffer d_frames points to (the pointer and the box scale travel
+ * through a small device parameter block written in stream order in front of
+ * the graph): handing over a fresh buffer per call costs nothing extra. */
 int ffgpu_exec_forward_dev(ffgpu_exec *ex, const float *d_frames, void *stream);
 
 /* Same, from host memory (H2D copy included), then waits for completion. */
@@ -115,12 +124,18 @@ int ffgpu_exec_set_ring(ffgpu_exec *ex, void *dev_ring, int slots);
 int ffgpu_exec_set_ring_strided(ffgpu_exec *ex, void *dev_ring, int slots, int slot_records);
 /* Synchronise the executor's last stream and copy the records to the host. */
 int ffgpu_exec_read_dets(ffgpu_exec *ex, ffgpu_frame_dets *host_out, int max_frames);
+/* ALL boxes of `frame` that survived NMS, score order, source-image coordinates (what the reference leaves in
+ * net->bbox_list[0..bbox_num)): copies min(nfull, cap) of them and returns nfull.  Synchronises like read_dets. */
+int ffgpu_exec_read_boxes(ffgpu_exec *ex, int frame, BBOX *host_out, int cap);
+int ffgpu_exec_cand_capacity(const ffgpu_exec *ex);     /* candidate slots per frame (see above)                       */
+int ffgpu_exec_graph_captures(const ffgpu_exec *ex);    /* HIP graphs captured so far by this executor (1 after any    */
+                                                        /* number of forwards on any number of buffers)                */
 
 /* FFGPU_KEEP_ALL executors only: copy layer `layer`'s OUTPUT for frame `frame`
  * into host_out (oc*oh*ow floats, reference CHW order).  layer == -1 gives the
  * network input as the first layer saw it.  Pre-NMS candidates: layer == -2
- * writes up to FFGPU_MAX_CAND BBOX (in network pixels, reference emission
- * order) and returns their count. */
+ * writes the frame's candidates (up to ffgpu_exec_cand_capacity() BBOX, in network
+ * pixels, reference emission order) and returns their count. */
 int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float *host_out, size_t cap_floats);
 
 /* Mean device time per layer KIND over the last profiled forward, in micro-
@@ -149,9 +164,9 @@ enum {
     FFGPU_K_DW_STREAM = 2,    /* depthwise 3x3 s1: register sliding window, 16 B loads    */
     FFGPU_K_DW_LDS = 3,       /* depthwise 3x3/5x5, s1/s2: whole planes staged in LDS     */
     FFGPU_K_PW_MFMA = 4,      /* 1x1: fp32 MFMA 16x16x4, streaming (bandwidth-bound)      */
-    FFGPU_K_PW_GEMM = 5,      /* 1x1: LDS-tiled fp32 MFMA 32x32x2 GEMM (compute-bound)    */
-    FFGPU_K_PW_VALU = 6,      /* 1x1: plain VALU FMA (baseline / tiny channel counts)     */
-    FFGPU_K_DENSE_SMALL = 7   /* dense 3x3/5x5 with <= 8 input channels (the first layer)   */
+    FFGPU_K_PW_GEMM = 5,      /* 1x1: fp32 MFMA GEMM tile for compute-bound shapes (ic, oc >= 128) */
+    FFGPU_K_DENSE_SMALL = 7,  /* dense 3x3/5x5 with <= 8 input channels (the first layer)   */
+    FFGPU_K_IGEMM = 8         /* dense KxK, groups == 1: implicit GEMM on fp32 MFMA (im2col gathered on the fly) */
 };
 
 /* name of the kernel `variant` resolves to for this shape (for logs/benches) */
@@ -175,17 +190,6 @@ float ffgpu_irb_dev(const float *d_in, const float *d_w1, const float *d_wd, con
                     const float *d_res, float *d_out, int batch, int iw, int ih, int ic, int ec, int oc,
                     int stride, int act1, int actd, int act2, int res_act, int warmup, int iters, void *stream);
 
-/* ---- diagnostics -------------------------------------------------------- */
-/* HBM stream calibration on this GPU: mean microseconds per pass over `bytes`
- * (16-byte lanes, grid-stride, `blocks` workgroups of 256).  mode 0: copy,
- * 1: copy with non-temporal loads+stores, 2: read only, 3: write only,
- * 4: copy, 4 independent 16-byte loads in flight per lane.  Used by bench.py
- * to report the measured copy ceiling next to the 8 TB/s spec. */
-float ffgpu_membench(void *d_dst, const void *d_src, size_t bytes, int mode, int blocks, int iters, void *stream);
-/* Pipe probe: every wave of `blocks` x 4 runs `iters` trips of n_mfma independent v_mfma_f32_16x16x4_f32 plus n_valu
- * independent v_fma_f32 (supported mixes: 16/0, 0/64, 16/64, 16/128, 0/128); returns microseconds per launch.  Shows
- * whether matrix-core and vector-ALU work of one wave / of several waves of a SIMD overlap. */
-float ffgpu_pipe_probe(int n_mfma, int n_valu, int blocks, int iters, void *stream);
 /* ---- compact records for the multi-GPU gather ("fixed-size detection records to rank 0"): the
  * `batch` records of each of `nslots` steps (slot s starts at record s * slot_stride_records of d_records, e.g. a ring
  * set with ffgpu_exec_set_ring) are packed into nslots blocks of ffgpu_packed_records_bytes(batch, cap) bytes:
@@ -194,10 +198,6 @@ float ffgpu_pipe_probe(int n_mfma, int n_valu, int blocks, int iters, void *stre
  * (over = 1, overflow |= 2 on the frames that lost boxes).  ffcnn_amd/dist.py unpacks them on the host. */
 size_t ffgpu_packed_records_bytes(int batch, int cap);
 int    ffgpu_pack_records(const void *d_records, int nslots, long slot_stride_records, int batch, int cap, void *d_out, void *stream);
-
-/* the same question with hand-placed instruction streams: mode 0 = 16 MFMAs per trip; 1 = each followed by `ns` plain
- * v_fma_f32; 2 = by ns/2 v_pk_fma_f32; 3 / 4 = the vector instructions alone.  Microseconds per launch. */
-float ffgpu_pipe_probe2(int mode, int ns, int blocks, int iters, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,35 @@
+/*
+ * ffcnn_hip_diag.h -- lab equipment, NOT part of the product ABI.
+ *
+ * These entry points live in their own library, ffcnn_amd/lib/libffcnn_hip_diag.so (built by the same Makefile from
+ * ffgpu_diag.hip): HBM stream calibration and the matrix-core / vector-ALU pipe probes that DESIGN.md quotes.  bench.py
+ * loads it (if present) to report the same-box copy rate next to the 8 TB/s spec; tools/ use the probes.
+ * libffcnn_hip.so exports none of them.  The launch-dropping switches FFGPU_DBG_SKIP / FFGPU_DBG_KEEP
+ * (tools/ablate_layers.py) exist only in a `make DIAG=1` build of the product library.
+ */
+#ifndef FFCNN_AMD_FFCNN_HIP_DIAG_H
+#define FFCNN_AMD_FFCNN_HIP_DIAG_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HBM stream calibration on this GPU: mean microseconds per pass over `bytes`
+ * (16-byte lanes, grid-stride, `blocks` workgroups of 256).  mode 0: copy,
+ * 1: copy with non-temporal loads+stores, 2: read only, 3: write only,
+ * 4: copy, 4 independent 16-byte loads in flight per lane.  Used by bench.py
+ * to report the measured copy ceiling next to the 8 TB/s spec. */
+float ffgpu_membench(void *d_dst, const void *d_src, size_t bytes, int mode, int blocks, int iters, void *stream);
+/* Pipe probe: every wave of `blocks` x 4 runs `iters` trips of n_mfma independent v_mfma_f32_16x16x4_f32 plus n_valu
+ * independent v_fma_f32 (supported mixes: 16/0, 0/64, 16/64, 16/128, 0/128); returns microseconds per launch.  Shows
+ * whether matrix-core and vector-ALU work of one wave / of several waves of a SIMD overlap. */
+float ffgpu_pipe_probe(int n_mfma, int n_valu, int blocks, int iters, void *stream);
+/* the same question with hand-placed instruction streams: mode 0 = 16 MFMAs per trip; 1 = each followed by `ns` plain
+ * v_fma_f32; 2 = by ns/2 v_pk_fma_f32; 3 / 4 = the vector instructions alone.  Microseconds per launch. */
+float ffgpu_pipe_probe2(int mode, int ns, int blocks, int iters, void *stream);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif

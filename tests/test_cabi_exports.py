@@ -27,6 +27,21 @@ def test_headers_and_exports_agree(capi):
         assert hasattr(L, sym), sym
 
 
+def test_lab_equipment_is_not_in_the_product(capi):
+    """ffcnn_hip_diag.h (membench, pipe probes) lives in its own library; the product .so exports none of it and no
+    launch-dropping debug switch is compiled into it"""
+    import ctypes as C
+    txt = open(os.path.join(ROOT, "include", "ffcnn_hip_diag.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    declared = set(re.findall(r"\b(ffgpu_[a-z0-9_]+)\s*\(", txt))
+    assert declared == set(capi.DIAG_EXPORTS)
+    D, L = C.CDLL(capi.diag_path()), capi.lib()
+    for sym in declared:
+        assert hasattr(D, sym) and not hasattr(L, sym), sym
+    blob = open(capi.library_path(), "rb").read()
+    assert b"FFGPU_DBG_SKIP" not in blob and b"FFGPU_DBG_KEEP" not in blob
+
+
 def test_struct_abi(capi):
     import ctypes as C
     assert (C.sizeof(capi.LAYER), C.sizeof(capi.BBOX), C.sizeof(capi.NET)) == (120, 24, 104)

@@ -68,3 +68,29 @@ def test_random_groupconv_vs_v2_im2col(need_ref):
             assert np.array_equal(orc.groupconv(x, f, g, p, s, fs, 2), r.groupconv(x, f, g, p, s, fs, 2))
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("bbox_max", [0, 700, 40])
+def test_candidate_capacity_regimes_bit_exact(need_ref, test_image, bbox_max):
+    """ignore_thresh = 0 (1 500 candidates per frame, hundreds of boxes after NMS) and net->bbox_max lowered until the
+    reference's emission-order truncation bites (ffcnn.c:463): the oracle's candidate cap reproduces both bit for bit"""
+    orc = need_ref
+    bgr, w, h = test_image
+    o, r = orc.Oracle(), orc.Ref("v0")
+    try:
+        for i in range(o.nlayers):
+            if o.layer(i).kind == 7:
+                o.layer(i).thresh = 0.0
+                r.layer(i).ignore_thres = 0.0
+        if bbox_max:
+            o.n.cap = bbox_max
+            r.n.bbox_max = bbox_max
+        o.set_input_image(bgr, w, h)
+        r.set_input_image(bgr, w, h)
+        o.forward(0)
+        r.forward()
+        assert o.n.ncand == (bbox_max or 1500)
+        assert o.boxes.tobytes() == r.boxes.tobytes() and len(o.boxes) > (100 if not bbox_max else 5)
+    finally:
+        o.close()
+        r.close()

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ffcnn_amd import capi
-L = capi.lib()
+L = capi.diag()
 it = 2000
 print("waves/SIMD  mfma16  valu64  mfma16+valu64  valu128  mfma16+valu128   (us; 16 MFMA = 512 cycles, 64 FMA = 256 cycles of issue)")
 for wps in (1, 2, 4):

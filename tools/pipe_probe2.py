@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ffcnn_amd import capi
-L = capi.lib()
+L = capi.diag()
 it = 2000
 for wps in (1, 2, 4):
     blocks = 256 * wps

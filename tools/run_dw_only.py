@@ -16,7 +16,7 @@ torch.cuda.synchronize()
 s = torch.cuda.Stream()
 nbytes = x.numel() * 4
 for _ in range(3):
-    capi.lib().ffgpu_membench(y.data_ptr(), x.data_ptr(), nbytes, 0, 1024, 1, s.cuda_stream)       # 3 launches each (2 warm + 1)
+    capi.diag().ffgpu_membench(y.data_ptr(), x.data_ptr(), nbytes, 0, 1024, 1, s.cuda_stream)       # 3 launches each (2 warm + 1)
     capi.groupconv_dev(x.data_ptr(), f.data_ptr(), y.data_ptr(), N, W, H, C, C, 1, 1, 3, C, act=2, stream=s.cuda_stream)
 torch.cuda.synchronize()
 print("bytes per launch (read) =", nbytes, "(written) =", nbytes)

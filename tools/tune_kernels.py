@@ -67,7 +67,7 @@ def mem(nbytes=1677721600):
     names = {0: "copy", 1: "copy nt", 2: "read", 3: "write", 4: "copy x4", 5: "wave-span", 6: "block-span", 7: "wave-span nt"}
     for mode in (0, 1, 5, 7, 6):
         for blocks in (256, 512, 768, 1024, 1280, 1536, 2048, 4096):
-            us = capi.lib().ffgpu_membench(b.data_ptr(), a.data_ptr(), nbytes, mode, blocks, 10, s.cuda_stream)
+            us = capi.diag().ffgpu_membench(b.data_ptr(), a.data_ptr(), nbytes, mode, blocks, 10, s.cuda_stream)
             moved = nbytes * (1 if mode in (2, 3) else 2)
             print("membench %-8s blocks=%5d  %8.1f us  %7.1f GB/s" % (names[mode], blocks, us, moved / us / 1e3))
 
