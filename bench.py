@@ -9,8 +9,10 @@ One "step" = one pass of the whole hot path (first conv ... YOLO decode + NMS)
 over one batch of 64 synthetic 320x320x3 frames PER GPU, inputs resident in HBM,
 ending with the NMS'd boxes of every frame of the job in host memory on rank 0
 (RCCL gather of the fixed-size per-frame detection records for N > 1).  Weak
-scaling: the global batch is 64*N.  Weights are broadcast from rank 0 over RCCL
-once, before the timed region.
+scaling by default: the global batch is 64*N.  `--global-batch 256` is BASELINE
+config[4] as written (strong scaling): every step is the SAME 256 frames, cut
+into contiguous shards of 256/N per GPU (ffcnn_amd.dist.shard_range).  Weights
+are broadcast from rank 0 over RCCL once, before the timed region.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement"):
   value        whole-job frames/s
@@ -167,16 +169,18 @@ def kernel_roofline(torch, capi, stream):
     copy_us = min(capi.diag().ffgpu_membench(y.data_ptr(), x.data_ptr(), alg_bytes // 2, 0, b, 10, stream.cuda_stream) for b in (1024, 2048))
     read_us = capi.diag().ffgpu_membench(y.data_ptr(), x.data_ptr(), alg_bytes // 2, 2, 2048, 10, stream.cuda_stream)
     gbs = alg_bytes / (us * 1e-6) / 1e9
-    traffic = None
+    traffic = traffic_source = None
     tf = os.path.join(ROOT, "profiles", "dw3x3_traffic.json")     # per-launch HBM bytes from the PMC passes
     if os.path.exists(tf):
         try:
             traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            # NOT measured by this run: rocprofv3 PMC passes cannot run inside the timed process
+            traffic_source = "profiles/dw3x3_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh, same kernel and shape; a cited constant, not collected by this run)"
         except (ValueError, OSError):
             traffic = None
     del x, y
     return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "us_per_launch": round(us, 2),
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source, "us_per_launch": round(us, 2),
             "algorithmic_bytes": alg_bytes, "workload": "dw3x3 s1 p1 320x320x64 batch 64 fp32 (BASELINE config[1])",
             "same_box_copy_GBs": round(alg_bytes / copy_us / 1e3, 1), "same_box_read_GBs": round(alg_bytes / 2 / read_us / 1e3, 1)}
 
@@ -209,14 +213,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-chain latency and the u8-input rate (N = 1 only, untimed extras)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the multi-GPU step (RCCL gather of the records on a side stream) even with one rank")
     ap.add_argument("--streams", type=int, default=4,
                     help="executors (one stream each) that take the batches in turn: up to that many batches are in flight")
     ap.add_argument("--input-sets", type=int, default=8, help="distinct synthetic batches resident in HBM, used in turn (8 x 78.6 MB does not fit the 256 MB Infinity Cache: every step reads its frames from HBM)")
     ap.add_argument("--split", action="store_true", help="FFGPU_SPLIT2 executors (two half-batch chains per batch)")
-    ap.add_argument("--gather-every", type=int, default=64,
-                    help="multi-GPU: steps whose records travel in one RCCL gather (fewer, larger collectives)")
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="multi-GPU: steps whose records travel in one RCCL gather (fewer, larger collectives); 0 = 64, "
+                         "or less when --steps is small so that a short run still ships full groups")
+    ap.add_argument("--global-batch", type=int, default=int(os.environ.get("FFCNN_BENCH_GLOBAL_BATCH", "0")),
+                    help="strong scaling (BASELINE config[4]: 256): a step is this many frames in total, cut into contiguous "
+                         "shards of global/N per GPU; 0 = weak scaling, 64 frames per GPU")
     args = ap.parse_args()
 
     import torch
@@ -238,7 +247,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    B = FRAMES_PER_GPU
+    strong = args.global_batch > 0
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch %d is not a multiple of %d GPUs (the gather moves equal-sized shards)" % (args.global_batch, world))
+        lo, hi = ffdist.shard_range(args.global_batch, rank, world)      # this rank's contiguous frames of every step
+        B = hi - lo
+    else:
+        lo, B = rank * FRAMES_PER_GPU, FRAMES_PER_GPU
+    G = args.global_batch if strong else B * world
     stream = torch.cuda.Stream()
     roof = roof_pw = None
     net = capi.Net()
@@ -251,24 +268,27 @@ def main():
         wt.copy_(wtmp)
         torch.cuda.synchronize()
         net.weights_commit()                 # refresh the packed LDS images derived from the filter rows
-    # One executor per GPU.  Single GPU: the NMS kernel writes the records straight into a pinned host mirror
+    # One executor per chain.  Single GPU: the NMS kernel writes the records straight into a pinned host mirror
     # (FFGPU_HOST_DETS), so the boxes are on the host when the step ends with no copy between two graph launches.
     # Several GPUs: the library's NMS kernel also writes each forward's records into a slot of a device ring
     # (ffgpu_exec_set_ring; nothing but graph launches sits on the compute stream); every --gather-every steps a side
-    # stream gathers the finished group over RCCL (one 12 MB message per rank instead of sixty-four 200 KB ones: xGMI
+    # stream gathers the finished group over RCCL (one message per rank and group instead of one per step: xGMI
     # collectives are latency-bound at this size) and moves the gathered block to rank 0's host while the next
-    # forwards already run.  A cross-stream hand-over costs the compute stream ~0.4 ms on this stack (measured with one
-    # rank, split executor: 0.716 / 0.698 / 0.695 ms per step for groups of 32 / 64 / 128, 0.682 without),
-    # which is why it is paid per group; the boxes of a step reach rank 0 at most one group (~45 ms) later, and the
-    # last, partial group is flushed inside the timed region.
+    # forwards already run.  The boxes of a step reach rank 0 at most one group later, and the last, partial group is
+    # flushed inside the timed region.
     gather_mode = world > 1 or args.force_gather
     host_dets = not gather_mode
     # Batches are independent, so consecutive steps go to S executors on S streams in turn (each its own arena and graph,
     # no events between them).  The chains run in lockstep (tools/ramp.py): S copies of every launch are on the device
-    # together and fill the SIMDs that one 64-frame launch leaves idle -- 0.69 ms per 64 frames with one chain, 0.44 with
-    # two, 0.36 with four.  The head branch inside a chain is off here.
+    # together and fill the SIMDs that one launch leaves idle.  The head branch inside a chain is off.
     S = max(1, args.streams)
-    if gather_mode and 2 * max(1, args.gather_every) % S:
+    M = args.gather_every
+    if M <= 0:                                                  # groups a short run can fill at least once
+        M = 64
+        while M > S and 2 * M > max(args.steps, 2 * S):
+            M //= 2
+    M = max(M, (S + 1) // 2)
+    if gather_mode and (2 * M) % S:
         raise SystemExit("--gather-every * 2 must be a multiple of --streams")
     os.environ.setdefault("FFGPU_BRANCH", "0" if S > 1 else "1")
     flags = (capi.FFGPU.HOST_DETS if host_dets else 0) | (capi.FFGPU.SPLIT2 if args.split else 0)
@@ -277,35 +297,44 @@ def main():
     exs = [net.executor(B, flags) for _ in range(S)]
     streams = [stream] + [torch.cuda.Stream() for _ in range(S - 1)]
     ex = exs[0]
+    model_bytes, model_flops = ex.work_model()
 
-    # synthetic frames (seeded per rank); frame 0 of rank 0 is the letterboxed test.bmp so boxes can be checked
-    g = torch.Generator(device="cuda").manual_seed(1236 + rank)
-    x = torch.rand((B, 3, 320, 320), device="cuda", generator=g)
+    # synthetic frames: the GLOBAL batch is seeded once (every rank draws the same stream and keeps its shard, so the strong-
+    # scaling job processes the same 256 frames whatever N is); frame 0 of the job is the letterboxed test.bmp
     check = None
+    K_in = max(1, args.input_sets)
+    xs = []
+    g = torch.Generator(device="cuda").manual_seed(1236)
+    img = None
     if rank == 0:
         # frame 0 = data/test.bmp through the library's own net_input; expected boxes are the
         # reference's (tests/golden/boxes.json, produced by the unmodified reference build)
         try:
             bgr, w, h = capi.load_bmp(os.path.join(ROOT, "data", "test.bmp"))
             net.set_input_image(bgr, w, h)
-            x[0] = torch.from_numpy(net.input.copy()).cuda()
+            img = torch.from_numpy(net.input.copy()).cuda()
             check = json.load(open(os.path.join(ROOT, "tests", "golden", "boxes.json")))["net_320x320_v0"]["boxes"]
         except Exception as e:
             print("bench: golden check unavailable: %r" % (e,), file=sys.stderr)
     # the steps take K distinct batches in turn (frame 0 is the test image in each of them, the rest differs): one batch used
     # over and over would sit in the 256 MB Infinity Cache and the first layer would never read HBM
-    K_in = max(1, args.input_sets)
-    xs = [x]
-    for k in range(1, K_in):
-        xk = torch.rand((B, 3, 320, 320), device="cuda", generator=g)
-        xk[0] = x[0]
+    for k in range(K_in):
+        xk = torch.empty((B, 3, 320, 320), device="cuda")
+        for c0 in range(0, G, 64):                              # the global batch in chunks; keep what falls into [lo, lo + B)
+            cn = min(64, G - c0)
+            chunk = torch.rand((cn, 3, 320, 320), device="cuda", generator=g)
+            a, b = max(c0, lo), min(c0 + cn, lo + B)
+            if a < b:
+                xk[a - lo:b - lo] = chunk[a - c0:b - c0]
+            del chunk
+        if img is not None:
+            xk[0] = img
         xs.append(xk)
+    x = xs[0]
     for e in exs:
         e.set_scale(640, 320)   # every frame is treated as a 640-wide source letterboxed to 320 (test.bmp's ratio)
 
     dptr, dbytes = ex.dets_dev()
-    dets = dev_tensor(torch, dptr, dbytes)                      # this rank's records (uint8 view of the library's buffer)
-    M = max(1, args.gather_every)
     # ring of two groups of M slots: the library's NMS kernel writes forward k's records into slot k % 2M itself
     # (ffgpu_exec_set_ring), so nothing but graph launches sits on the compute stream
     ring = torch.empty((2, M, dbytes), dtype=torch.uint8, device="cuda") if gather_mode else None
@@ -367,14 +396,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # every executor captures its graph on its first forward: do that once per executor before anything is counted
-    # (with --warmup smaller than --streams some captures would otherwise land inside the timed region)
-    for j in range(S):
-        exs[j].forward_dev(x.data_ptr(), streams[j].cuda_stream)
+    # One HIP graph per executor, captured on its first forward and valid for every input buffer (the input pointer travels
+    # through the executor's device parameter block): every (executor, input set) pair runs once here anyway, so nothing of
+    # a first use -- graph capture, page mapping of a fresh buffer -- can land inside the timed region
+    for k in range(max(K_in, S)):
+        for j in range(S):
+            exs[j].forward_dev(xs[k % K_in].data_ptr(), streams[j].cuda_stream)
     torch.cuda.synchronize()
+    assert all(e.graph_captures == 1 for e in exs)
     if gather_mode:                                             # ... and RCCL sets its communicator up on the first collective
+        restart()
         with torch.cuda.stream(comm):
             ffdist.gather_records(dist, cring[0].view(-1), dst=0, out=glist)
+        torch.cuda.synchronize()
+    # The single-kernel rooflines (BASELINE config[1] / config[2]) are measured HERE, between set-up and the net's warm-up:
+    # (a) after the executors exist -- the 3.4 GB + 0.3 GB these measurements allocate and free, taken first, left the
+    # library's arenas on worse-placed memory (the same net then ran 15 % slower); (b) before the timed net -- the device
+    # comes out of them in its sustained clock / memory state.  After idle it needs ~10 ms of work to get there
+    # (tools/short_run.py: 20 steps straight after a 50 ms pause run at 153 k frames/s, the same 20 steps back to back at
+    # 182 k), which a 5-step warm-up (1.8 ms) does not provide; both measurements are independent of the net's.
+    if world == 1 and not args.no_kernel_roofline:
+        roof = kernel_roofline(torch, capi, stream)
+        roof_pw = pw_roofline(torch, capi, stream)
         torch.cuda.synchronize()
     # warm-up and timed steps are numbered from 0 each, so both start on a fresh group and end with a flush
     restart()
@@ -395,9 +438,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
-        fps = B * world * args.steps / dt
+        fps = G * args.steps / dt
         ok = None
         if check is not None:
             if host_dets:
@@ -409,39 +453,68 @@ def main():
             ok = bool(len(got) == len(check) and all(
                 int(a["type"]) == int(b["type"]) and abs(float(a["score"]) - float(b["score"])) < 1e-4 and
                 max(abs(float(a[k]) - float(b[k])) for k in ("x1", "y1", "x2", "y2")) < 0.05 for a, b in zip(got, check)))
+        per_gpu_s = dt / args.steps                             # seconds per step; every GPU handles B frames of it
         out = {
-            "metric": "frames/sec yolo-fastest-1.1 @320x320 batch-64 per GPU (full forward: conv stack + YOLO decode + NMS, boxes on rank 0)",
+            "metric": "frames/sec yolo-fastest-1.1 @320x320 batch-64 per GPU (full forward: conv stack + YOLO decode + NMS, boxes on rank 0)"
+                      if not strong else
+                      "frames/sec yolo-fastest-1.1 @320x320 global batch %d sharded over the GPUs (full forward + boxes on rank 0)" % G,
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[3]/[4])",
-                       "frames_per_gpu": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+            "config": {"workload": ("yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[3])" if not strong else
+                                    "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM, global batch %d in contiguous shards (BASELINE config[4])" % G),
+                       "frames_per_gpu": B, "global_batch": G, "parallelism": "dp%d" % world,
                        "input_sets": K_in,
-                       # unfused activation traffic 60.11 MB per frame -> 3.85 GB per 64-frame batch ->
-                       # 0.48 ms at 8 TB/s -> 133 k frames/s per GPU if every layer ran at the HBM roofline UNFUSED
-                       "frac_of_unfused_hbm_ceiling": round(fps / world / (8.0e12 / 60.11e6), 4),
                        "launches_per_step": ex.kernel_count, "arena_MB": round(ex.arena_bytes / 2**20, 1),
                        "executors": S, "pipelining": "%d executors on %d streams take the batches in turn%s" % (S, S, ", each split in two half-batch chains" if args.split else ""), "gather": ("RCCL gather of %d steps' records (packed: %d bytes per step and rank) + D2H on a side stream, overlapped with the next steps" % (M, pbytes)) if gather_mode else "records written to pinned host memory by the NMS kernel",
+                       "graph_captures_per_executor": max(e.graph_captures for e in exs),
                        "weights": "data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL, untimed)",
                        "boxes_match_reference_golden_frame0": ok},
+            # the whole net against the two ceilings that exist for it (per GPU): what the FUSED launch list must move
+            # (each launch's inputs + outputs + filter rows once: ffgpu_exec_work_model) at the HBM peak, and the conv
+            # stack's multiply-adds at the fp32 matrix peak.  Neither bounds the net tightly -- most launches are bound
+            # by a wave's serial chain of MFMA + VALU issue -- but they are the honest denominators.
+            "roofline_net": {"fused_algorithmic_bytes_per_batch": int(model_bytes), "hbm_GBs": round(model_bytes / per_gpu_s / 1e9, 1),
+                             "hbm_frac": round(model_bytes / per_gpu_s / 1e9 / HBM_PEAK_GBS, 4),
+                             "flops_per_batch": int(model_flops), "TFLOPs": round(model_flops / per_gpu_s / 1e12, 2),
+                             "mfma_f32_frac": round(model_flops / per_gpu_s / 1e12 / FP32_MFMA_PEAK_TF, 4),
+                             "batch": B},
         }
-        if world == 1 and not args.no_kernel_roofline:
-            # the single-kernel rooflines run AFTER the net (executors released): the 3.4 GB + 0.3 GB they allocate and
-            # free first leave the library's arenas on worse-placed memory -- the same net then runs 15 % slower
-            # (119 k vs 141 k frames/s); the roofline kernels themselves do not care about the order
-            for e in exs:
-                e.close()
-            exs = []
-            torch.cuda.synchronize()
-            roof = kernel_roofline(torch, capi, stream)
-            roof_pw = pw_roofline(torch, capi, stream)
+        if roof is not None:
             out["roofline"] = roof
             out["roofline_pw"] = roof_pw
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["gpu_vs_cpu_1thread"] = round(fps / out["cpu_baseline"]["value"], 1) if out["cpu_baseline"]["value"] else None
-    else:
-        out = None
+    # untimed extras (N = 1): one chain alone (latency of a batch), and the same job fed with u8 BGR frames (SURVEY 8(d) row 4:
+    # "64 frames u8 BGR 320x320") through ffgpu_exec_forward_bgr_dev -- the letterbox / normalise kernel in front of the net
+    if rank == 0 and world == 1 and not gather_mode and not args.no_extras:
+        torch.cuda.synchronize()
+        nlat = 30
+        for i in range(5):
+            exs[0].forward_dev(xs[i % K_in].data_ptr(), streams[0].cuda_stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(nlat):
+            exs[0].forward_dev(xs[i % K_in].data_ptr(), streams[0].cuda_stream)
+        torch.cuda.synchronize()
+        out["roofline_net"]["single_chain_ms_per_batch"] = round((time.perf_counter() - t1) / nlat * 1e3, 4)
+        gu = torch.Generator(device="cuda").manual_seed(1236)
+        us = [torch.randint(0, 256, (B, 320, 960), dtype=torch.uint8, device="cuda", generator=gu) for _ in range(K_in)]
+        n8 = max(S, min(args.steps, 200) // S * S)
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(n8):
+                exs[i % S].forward_bgr_dev(us[i % K_in].data_ptr(), 320, 320, stream=streams[i % S].cuda_stream)
+            torch.cuda.synchronize()
+            t8 = time.perf_counter() - t1
+        out["config"]["u8_bgr_input"] = {"value": round(B * n8 / t8, 1), "unit": "frames/s", "steps": n8,
+                                         "what": "same job, %d u8 BGR 320x320 frames per step resident in HBM -> ffgpu_exec_forward_bgr_dev (batched net_input kernel + the net)" % B}
+        del us
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        for e in exs:
+            e.close()
+        exs = []
+        out["cpu_baseline"] = cpu_baseline()
+        out["gpu_vs_cpu_1thread"] = round(fps / out["cpu_baseline"]["value"], 1) if out["cpu_baseline"]["value"] else None
     for e in exs:
         e.close()
     net.close()

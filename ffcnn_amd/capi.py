@@ -60,7 +60,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_device_count", "ffgpu_set_device", "ffgpu_last_error", "ffgpu_build_info",
            "ffgpu_net_weights_dev", "ffgpu_net_weights_commit",
            "ffgpu_exec_create", "ffgpu_exec_destroy", "ffgpu_exec_batch", "ffgpu_exec_arena_bytes",
-           "ffgpu_exec_kernel_count", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
+           "ffgpu_exec_kernel_count", "ffgpu_exec_work_model", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
            "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_set_ring", "ffgpu_exec_set_ring_strided", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
            "ffgpu_exec_read_boxes", "ffgpu_exec_cand_capacity", "ffgpu_exec_graph_captures",
            "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records"]
@@ -115,6 +115,7 @@ def lib():
     L.ffgpu_exec_arena_bytes.restype = sz
     L.ffgpu_exec_arena_bytes.argtypes = [vp]
     L.ffgpu_exec_kernel_count.argtypes = [vp]
+    L.ffgpu_exec_work_model.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ffgpu_exec_set_scale.argtypes = [vp, i, i]
     L.ffgpu_exec_forward_dev.argtypes = [vp, vp, vp]
     L.ffgpu_exec_forward_host.argtypes = [vp, f32p]
@@ -329,6 +330,12 @@ class Executor:
     @property
     def kernel_count(self):
         return lib().ffgpu_exec_kernel_count(self.h)
+
+    def work_model(self):
+        """(HBM bytes, flops) one forward of this plan must move / compute"""
+        b, f = C.c_double(), C.c_double()
+        _check(lib().ffgpu_exec_work_model(self.h, C.byref(b), C.byref(f)), "ffgpu_exec_work_model")
+        return b.value, f.value
 
     def set_scale(self, s1, s2):
         _check(lib().ffgpu_exec_set_scale(self.h, s1, s2), "ffgpu_exec_set_scale")

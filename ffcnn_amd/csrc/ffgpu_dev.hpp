@@ -65,8 +65,10 @@ int    ffgpu_pw_pack(const ConvDesc &d, float *pk, hipStream_t s);
 struct ExecParams {
     const float *frames;      // this forward's batch input (frame-major N x C x H x W)
     int s1, s2;               // box rescale ratio (ffcnn.c:267-273), applied by k_nms
+    ffgpu_frame_dets *ring;   // record ring of the multi-GPU gather (ffgpu_exec_set_ring), or NULL
+    int ring_slots, ring_stride;
 };
-int  ffgpu_launch_set_params(ExecParams *d_prm, const float *frames, int s1, int s2, hipStream_t s);
+int  ffgpu_launch_set_params(ExecParams *d_prm, const ExecParams &v, hipStream_t s);
 bool ffgpu_conv_supports_ind(const ConvDesc &d);    // the kernel ffgpu_launch_conv would pick reads ConvDesc::in_ind
 
 // kernels.hip
@@ -94,8 +96,7 @@ int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand,
 // bbox_max: the reference stops appending candidates at net->bbox_max in emission order (ffcnn.c:463); same here
 // scratch (cap_pow2 > FFGPU_NMS_LDS_CAP only): 12 bytes x cap_pow2 per frame of global memory instead of LDS
 int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, int bbox_max, BBOX *full, void *scratch,
-                     ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
-                     ffgpu_frame_dets *ring, int ring_slots, int ring_stride, const int *ring_ctr, int N,
+                     ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, const int *ring_ctr, int N,
                      float thresh, int use_min, const ExecParams *prm, hipStream_t s);
 #define FFGPU_NMS_LDS_CAP 8192
 int ffgpu_launch_clear(int *ncand, int N, int *ring_ctr, hipStream_t s);

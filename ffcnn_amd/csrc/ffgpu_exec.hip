@@ -120,7 +120,7 @@ struct ffgpu_exec {
     void  *d_nms_scratch = nullptr;    // k_nms work arrays when they do not fit LDS
     ExecParams *d_prm = nullptr;       // device parameter block: input pointer + box scale of the forward being enqueued
     bool   indirect = false;           // every launch that reads the batch input does so through d_prm->frames
-    const float *prm_frames = nullptr; int prm_s1 = 0, prm_s2 = 0; hipStream_t prm_stream = nullptr; bool prm_valid = false;
+    ExecParams prm_sent = {}; hipStream_t prm_stream = nullptr; bool prm_valid = false;      // what d_prm holds (or will, on prm_stream)
     const float *last_frames = nullptr;   // input of the last forward (read_layer(-1))
     ffgpu_frame_dets *d_dets = nullptr;
     ffgpu_frame_dets *h_dets = nullptr, *h_dets_dev = nullptr;   // FFGPU_HOST_DETS: pinned mirror and its device address
@@ -545,7 +545,7 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
 #endif
     switch (st.kind) {
     case S_CLEAR:
-        return ffgpu_launch_clear(ex->d_ncand, ex->N, ex->ring ? ex->d_ringctr : nullptr, s);
+        return ffgpu_launch_clear(ex->d_ncand, ex->N, ex->d_ringctr, s);
     case S_CONV: {
         ConvDesc d = st.conv;
         if (st.in_is_input && !d.in_ind) d.in = d_frames;
@@ -579,11 +579,10 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
         return ffgpu_launch_front(d, st.irb, s); }
     case S_YOLO:
         return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->cand_cap,
-                                 (st.flag && ex->ring) ? ex->d_ringctr : nullptr, s);
+                                 st.flag ? ex->d_ringctr : nullptr, s);          // forwards are counted whether or not a ring is attached
     case S_NMS:
         return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->cand_cap, ex->bbox_max, ex->d_full, ex->d_nms_scratch,
-                                ex->d_dets, ex->h_dets_dev, ex->ring, ex->ring_slots, ex->ring_stride ? ex->ring_stride : ex->N,
-                                ex->d_ringctr, ex->N, 0.5f, 1, ex->d_prm, s);
+                                ex->d_dets, ex->h_dets_dev, ex->d_ringctr, ex->N, 0.5f, 1, ex->d_prm, s);
     }
     return -1;
 }
@@ -646,9 +645,13 @@ static int push_params(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
         return 0;
     }
     ex->last_frames = d_frames;
-    if (ex->prm_valid && ex->prm_frames == d_frames && ex->prm_s1 == ex->s1 && ex->prm_s2 == ex->s2 && ex->prm_stream == s) return 0;
-    if (ffgpu_launch_set_params(ex->d_prm, d_frames, ex->s1, ex->s2, s)) return -1;
-    ex->prm_frames = d_frames; ex->prm_s1 = ex->s1; ex->prm_s2 = ex->s2; ex->prm_stream = s; ex->prm_valid = true;
+    ExecParams v;
+    memset(&v, 0, sizeof v);
+    v.frames = d_frames; v.s1 = ex->s1; v.s2 = ex->s2;
+    v.ring = ex->ring; v.ring_slots = ex->ring_slots; v.ring_stride = ex->ring_stride ? ex->ring_stride : ex->N;
+    if (ex->prm_valid && ex->prm_stream == s && memcmp(&v, &ex->prm_sent, sizeof v) == 0) return 0;
+    if (ffgpu_launch_set_params(ex->d_prm, v, s)) return -1;
+    ex->prm_sent = v; ex->prm_stream = s; ex->prm_valid = true;
     return 0;
 }
 
@@ -847,6 +850,51 @@ extern "C" int ffgpu_exec_batch(const ffgpu_exec *ex) { return ex ? ex->N : 0; }
 extern "C" size_t ffgpu_exec_arena_bytes(const ffgpu_exec *ex) { return ex ? ex->arena_floats * sizeof(float) : 0; }
 extern "C" int ffgpu_exec_kernel_count(const ffgpu_exec *ex) { return ex ? ex->kernel_count : 0; }
 
+// What one forward of this plan MUST move and compute: per launch the tensors it reads and writes once each (input,
+// output, residual, filter rows; nothing for the tensors a fused launch keeps on chip), summed over the launch list; and
+// 2 x multiply-adds of every conv layer of the net (fused or not).  bench.py prices the measured time per batch against
+// these two numbers (HBM peak, fp32 matrix peak).
+extern "C" int ffgpu_exec_work_model(const ffgpu_exec *ex, double *hbm_bytes, double *flops)
+{
+    if (!ex || !ex->net) { ffgpu_set_error("work_model: bad executor"); return -1; }
+    double by = 0, fl = 0;
+    if (ex->child[0]) {
+        for (int c = 0; c < ex->nchild; c++) {
+            double b1 = 0, f1 = 0;
+            if (ffgpu_exec_work_model(ex->child[c], &b1, &f1)) return -1;
+            by += b1; fl += f1;
+        }
+    } else {
+        const double N = ex->N;
+        auto rows = [](const ConvDesc &d) { return (double)d.oc * (conv_k4(d) + 4); };
+        for (const Step &st : ex->steps) {
+            switch (st.kind) {
+            case S_CONV: { const ConvDesc &d = st.conv;
+                by += 4.0 * (N * d.ic * d.ih * d.iw + N * d.oc * d.oh * d.ow * (d.residual ? 2 : 1) + rows(d)); break; }
+            case S_IRB: { const IrbDesc &d = st.irb;
+                by += 4.0 * (N * d.ic * d.H * d.W + N * d.oc * d.OH * d.OW * (d.residual ? 2 : 1) + (double)d.ec * (d.ic + 4 + 16) + (double)d.oc * (d.ec + 4)); break; }
+            case S_FRONT: { const ConvDesc &c = st.conv; const IrbDesc &d = st.irb;
+                by += 4.0 * (N * c.ic * c.ih * c.iw + N * d.oc * d.OH * d.OW + rows(c)); break; }
+            case S_POOL: { const int np = 1 + (st.fs2[0] != 0) + (st.fs2[1] != 0);
+                by += 4.0 * N * st.c * ((double)st.w * st.h + (double)np * (st.w / st.stride) * (st.h / st.stride)); break; }
+            case S_UPSAMPLE: by += 4.0 * N * st.c * (double)st.w * st.h * (1 + st.stride * st.stride); break;
+            case S_ADD: by += 4.0 * 3 * st.n; break;
+            case S_COPY: by += 4.0 * 2 * st.n; break;
+            case S_TOCNHW: by += 4.0 * 2 * N * st.c * (double)st.w * st.h; break;
+            case S_YOLO: by += 4.0 * N * 3 * (5 + st.head.classes) * (double)st.head.w * st.head.h; break;
+            default: break;
+            }
+        }
+        const LAYER *ll = ex->net->layer_list;
+        for (int i = 0; i < ex->net->layer_num; i++)
+            if (ll[i].type == LAYER_TYPE_CONV)
+                fl += 2.0 * N * ll[i].fs * ll[i].fs * (ll[i].c / ll[i].groups) * (double)ll[i + 1].c * ll[i + 1].w * ll[i + 1].h;
+    }
+    if (hbm_bytes) *hbm_bytes = by;
+    if (flops) *flops = fl;
+    return 0;
+}
+
 extern "C" int ffgpu_exec_set_scale(ffgpu_exec *ex, int s1, int s2)
 {
     if (!ex || s2 == 0) { ffgpu_set_error("set_scale: bad arguments"); return -1; }
@@ -907,8 +955,7 @@ extern "C" int ffgpu_exec_dets_dev(ffgpu_exec *ex, void **dev_ptr, size_t *bytes
 extern "C" int ffgpu_exec_set_ring_strided(ffgpu_exec *ex, void *dev_ring, int slots, int slot_records)
 {
     if (!ex || (dev_ring && (slots < 1 || slot_records < ex->N))) { ffgpu_set_error("set_ring: bad arguments"); return -1; }
-    FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
-    drop_graphs(ex);                                            // the ring pointer is a kernel argument of the graphs
+    FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));          // (the ring travels in the parameter block: the graph stays)
     ex->ring = (ffgpu_frame_dets *)dev_ring; ex->ring_slots = dev_ring ? slots : 0; ex->ring_stride = slot_records;
     FFGPU_CHECK(hipMemset(ex->d_ringctr, 0, sizeof(int)));
     for (int c = 0; c < ex->nchild; c++) {                      // each part writes its slice of every slot

@@ -315,8 +315,8 @@ __global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *
 template <bool GLB>
 __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, int cap_p2, int bbox_max,
                                              BBOX *full, unsigned char *scratch,
-                                             ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, ffgpu_frame_dets *ring, int ring_slots,
-                                             int ring_stride, const int *ring_ctr, float thresh, int use_min, const ExecParams *prm)
+                                             ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
+                                             const int *ring_ctr, float thresh, int use_min, const ExecParams *prm)
 {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_lds[];
@@ -327,6 +327,8 @@ __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_k
     unsigned char *s_alive = wb + (size_t)12 * cap_p2;
     const int n = blockIdx.x, tid = threadIdx.x;
     const int s1 = prm->s1, s2 = prm->s2;
+    ffgpu_frame_dets *const ring = prm->ring;                   // (the ring travels in the parameter block too: attaching or
+    const int ring_slots = prm->ring_slots, ring_stride = prm->ring_stride;   //  restarting it does not invalidate the graph)
     const int total = ncand[n];
     int m = min(total, cap);
     const BBOX *c = cand + (long)n * cap;
@@ -431,9 +433,9 @@ __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_k
 }
 
 // the executor's parameter block (ExecParams): rewritten in stream order in front of a graph launch
-__global__ void k_set_params(ExecParams *prm, const float *frames, int s1, int s2)
+__global__ void k_set_params(ExecParams *prm, ExecParams v)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { prm->frames = frames; prm->s1 = s1; prm->s2 = s2; }
+    if (threadIdx.x == 0 && blockIdx.x == 0) *prm = v;
 }
 
 // start of a forward: no candidates yet; one more forward for the record ring
@@ -528,8 +530,7 @@ int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand,
 }
 
 int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, int bbox_max, BBOX *full, void *scratch,
-                     ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
-                     ffgpu_frame_dets *ring, int ring_slots, int ring_stride, const int *ring_ctr, int N,
+                     ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, const int *ring_ctr, int N,
                      float thresh, int use_min, const ExecParams *prm, hipStream_t s)
 {
     int p2 = 1;
@@ -537,7 +538,7 @@ int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap,
     if (p2 > FFGPU_NMS_LDS_CAP) {
         if (!scratch) { ffgpu_set_error("nms: %d candidate slots per frame need the global scratch buffer", cap); return -1; }
         hipLaunchKernelGGL(k_nms<true>, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, cap, p2, bbox_max, full, (unsigned char *)scratch,
-                           dets, dets_host, ring, ring_slots, ring_stride, ring_ctr, thresh, use_min, prm);
+                           dets, dets_host, ring_ctr, thresh, use_min, prm);
     } else {
         const size_t lds = (size_t)13 * p2;
         static bool raised = false;                                // > 64 KB of dynamic LDS needs the attribute (once per process)
@@ -547,15 +548,15 @@ int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap,
             raised = true;
         }
         hipLaunchKernelGGL(k_nms<false>, dim3(N), dim3(256), lds, s, cand, cand_key, ncand, cap, p2, bbox_max, full, nullptr,
-                           dets, dets_host, ring, ring_slots, ring_stride, ring_ctr, thresh, use_min, prm);
+                           dets, dets_host, ring_ctr, thresh, use_min, prm);
     }
     LAUNCH_OK("nms");
     return 0;
 }
 
-int ffgpu_launch_set_params(ExecParams *d_prm, const float *frames, int s1, int s2, hipStream_t s)
+int ffgpu_launch_set_params(ExecParams *d_prm, const ExecParams &v, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, s, d_prm, frames, s1, s2);
+    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(1), 0, s, d_prm, v);
     LAUNCH_OK("set_params");
     return 0;
 }

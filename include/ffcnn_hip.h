@@ -85,6 +85,9 @@ void        ffgpu_exec_destroy(ffgpu_exec *ex);
 int         ffgpu_exec_batch(const ffgpu_exec *ex);
 size_t      ffgpu_exec_arena_bytes(const ffgpu_exec *ex);
 int         ffgpu_exec_kernel_count(const ffgpu_exec *ex);   /* launches per forward */
+/* What one forward of this plan must move and compute: bytes = per launch the tensors it reads / writes once each
+ * (fused launches keep their inner tensors on chip), flops = 2 x multiply-adds of every conv layer (ffcnn.c:374-379). */
+int         ffgpu_exec_work_model(const ffgpu_exec *ex, double *hbm_bytes, double *flops);
 
 /* Box rescale ratio for every frame of the batch (what net_input derives per
  * image, ffcnn.c:267-273).  Default s1 = s2 = 1 (boxes in network pixels). */
