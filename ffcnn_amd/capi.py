@@ -69,7 +69,7 @@ DIAG_EXPORTS = ["ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_pipe_probe2"]
 
 
 def library_path():
-    return os.path.join(HERE, "lib", "libffcnn_hip.so")
+    return os.environ.get("FFCNN_HIP_LIB") or os.path.join(HERE, "lib", "libffcnn_hip.so")     # (override: tuning builds)
 
 
 def build_library(force=False):

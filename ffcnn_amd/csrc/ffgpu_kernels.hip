@@ -11,6 +11,11 @@
 //   YOLO decode                        ffcnn.c:438-474
 //   NMS                                ffcnn.c:298-335
 //   net_input                          ffcnn.c:259-289
+#include <algorithm>
+#include <type_traits>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
 #include "ffgpu_dev.hpp"
 
 #define WAVE 64

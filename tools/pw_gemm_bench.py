@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""BASELINE config[2] (1x1, 256 -> 512, 20x20, batch 256) on the pointwise GEMM kernels: microseconds, TFLOP/s, fraction of
+the fp32 matrix peak; FFGPU_PWG_PX / FFGPU_PW_GEMM_OLD choose the variant."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ffcnn_amd import capi
+N, ic, oc, H, W = 256, 256, 512, 20, 20
+if len(sys.argv) > 1:
+    N, ic, oc, H, W = (int(v) for v in sys.argv[1:6])
+g = torch.Generator(device="cuda").manual_seed(1235)
+x = torch.rand((ic * N, H, W), device="cuda", generator=g) * 2 - 1
+y = torch.empty((oc * N, H, W), device="cuda")
+filt = torch.zeros((oc, ((ic + 3) & ~3) + 4), device="cuda")
+filt[:, :ic] = torch.rand((oc, ic), device="cuda", generator=g) - 0.5
+filt[:, (ic + 3) & ~3] = 1.0
+s = torch.cuda.Stream()
+for rep in range(3):
+    us = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2, warmup=5, iters=50, stream=s.cuda_stream)
+fl = 2.0 * oc * ic * N * H * W
+print("%s PX=%s old=%s: %.1f us  %.1f TFLOP/s  %.3f of 157.3" % (capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc), os.environ.get("FFGPU_PWG_PX", "2"),
+      os.environ.get("FFGPU_PW_GEMM_OLD", "0"), us, fl / us / 1e6, fl / us / 1e6 / 157.3))
