@@ -63,7 +63,9 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_kernel_count", "ffgpu_exec_work_model", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
            "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_set_ring", "ffgpu_exec_set_ring_strided", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
            "ffgpu_exec_read_boxes", "ffgpu_exec_cand_capacity", "ffgpu_exec_graph_captures",
-           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records"]
+           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records",
+           "ffgpu_shard_range", "ffgpu_node_create", "ffgpu_node_destroy", "ffgpu_node_ndev", "ffgpu_node_shard", "ffgpu_node_set_scale",
+           "ffgpu_node_input_dev", "ffgpu_node_forward", "ffgpu_node_forward_host"]
 # include/ffcnn_hip_diag.h (libffcnn_hip_diag.so: lab equipment, its own library)
 DIAG_EXPORTS = ["ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_pipe_probe2"]
 
@@ -142,6 +144,18 @@ def lib():
     L.ffgpu_packed_records_bytes.argtypes = [i, i]
     L.ffgpu_pack_records.restype = i
     L.ffgpu_pack_records.argtypes = [vp, i, C.c_long, i, i, vp, vp]
+    L.ffgpu_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
+    L.ffgpu_shard_range.restype = None
+    L.ffgpu_node_create.restype = vp
+    L.ffgpu_node_create.argtypes = [C.POINTER(NET), i, C.POINTER(i), i, i, i]
+    L.ffgpu_node_destroy.argtypes = [vp]
+    L.ffgpu_node_ndev.argtypes = [vp]
+    L.ffgpu_node_shard.argtypes = [vp, i, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.ffgpu_node_set_scale.argtypes = [vp, i, i]
+    L.ffgpu_node_input_dev.restype = vp
+    L.ffgpu_node_input_dev.argtypes = [vp, i]
+    L.ffgpu_node_forward.argtypes = [vp, vp]
+    L.ffgpu_node_forward_host.argtypes = [vp, f32p, vp]
     _lib = L
     return L
 
@@ -417,6 +431,58 @@ class Executor:
         us = (C.c_float * 8)()
         _check(lib().ffgpu_exec_profile(self.h, dev_ptr, us), "ffgpu_exec_profile")
         return list(us)
+
+
+def shard_range(total, rank, world):
+    lo, hi = C.c_int(), C.c_int()
+    lib().ffgpu_shard_range(total, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+class Node:
+    """ffgpu_node_*: one process, ndev GPUs (RCCL broadcast of the weights, gather of the records)"""
+    LOOPBACK = 1
+
+    def __init__(self, net, ndev, global_batch, devices=None, exec_flags=0, node_flags=0):
+        self.net, self.ndev, self.total = net, ndev, global_batch
+        dv = (C.c_int * ndev)(*devices) if devices is not None else None
+        self.h = lib().ffgpu_node_create(net.p, ndev, dv, global_batch, exec_flags, node_flags)
+        if not self.h:
+            raise RuntimeError("ffgpu_node_create failed: %s" % last_error())
+
+    def close(self):
+        if self.h:
+            lib().ffgpu_node_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def shard(self, rank):
+        lo, hi, dev = C.c_int(), C.c_int(), C.c_int()
+        _check(lib().ffgpu_node_shard(self.h, rank, C.byref(lo), C.byref(hi), C.byref(dev)), "ffgpu_node_shard")
+        return lo.value, hi.value, dev.value
+
+    def set_scale(self, s1, s2):
+        _check(lib().ffgpu_node_set_scale(self.h, s1, s2), "ffgpu_node_set_scale")
+
+    def input_dev(self, rank):
+        return lib().ffgpu_node_input_dev(self.h, rank)
+
+    def forward(self):
+        out = np.zeros(self.total, DETS_DTYPE)
+        _check(lib().ffgpu_node_forward(self.h, out.ctypes.data), "ffgpu_node_forward")
+        return out
+
+    def forward_host(self, frames):
+        frames = np.ascontiguousarray(frames, np.float32)
+        assert frames.shape == (self.total,) + self.net.input_shape, frames.shape
+        out = np.zeros(self.total, DETS_DTYPE)
+        _check(lib().ffgpu_node_forward_host(self.h, frames.ctypes.data_as(f32p), out.ctypes.data), "ffgpu_node_forward_host")
+        return out
 
 
 def groupconv_dev(d_in, d_filt, d_out, batch, iw, ih, ic, groups, pad, stride, fs, fn, act=0, flags=0, variant=0, stream=None):

@@ -103,7 +103,7 @@ struct ffgpu_netdev {
 struct ffgpu_exec {
     NET *net = nullptr;
     ffgpu_netdev *dev = nullptr;
-    int  N = 1, flags = 0;
+    int  N = 1, flags = 0, device = 0;
     int  in_c = 0, in_h = 0, in_w = 0;
     std::vector<Step>   steps;
     std::vector<Tensor> tensors;       // index = layer id
@@ -738,10 +738,18 @@ static ffgpu_netdev *netdev_of(NET *net)
     return (ffgpu_netdev *)ext->dev;
 }
 
+static ffgpu_exec *exec_create_on(ffgpu_netdev *dev, NET *net, int batch, int flags);
 extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
 {
     ffgpu_netdev *dev = netdev_of(net);
     if (!dev) return nullptr;
+    return exec_create_on(dev, net, batch, flags);
+}
+
+// (an executor lives on ONE device: that of the ffgpu_netdev -- the device copy of the weights -- it is planned on; a
+//  multi-GPU node holds one netdev + executor per device, ffgpu_node.inc)
+static ffgpu_exec *exec_create_on(ffgpu_netdev *dev, NET *net, int batch, int flags)
+{
     if (batch < 1) { ffgpu_set_error("batch must be >= 1"); return nullptr; }
     if (hipSetDevice(dev->device) != hipSuccess) { ffgpu_set_error("hipSetDevice failed"); return nullptr; }
     const char *env = getenv("FFCNN_COMPAT_V6");
@@ -754,7 +762,7 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
     const bool as_child = (flags & FFGPU_INTERNAL_CHILD) != 0;
     flags &= ~(FFGPU_SPLIT2 | FFGPU_INTERNAL_CHILD);
     ffgpu_exec *ex = new ffgpu_exec();
-    ex->net = net; ex->dev = dev; ex->N = batch; ex->flags = flags; ex->is_child = as_child;
+    ex->net = net; ex->dev = dev; ex->device = dev->device; ex->N = batch; ex->flags = flags; ex->is_child = as_child;
     ex->in_c = net->layer_list[0].c; ex->in_h = net->layer_list[0].h; ex->in_w = net->layer_list[0].w;
     // candidate slots per frame: one per anchor of every head cell, so the decode can never overflow; the reference's own
     // cap (bbox_max candidates in emission order, ffcnn.c:243,463) is applied by k_nms
@@ -793,7 +801,7 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
         const char *ek = getenv("FFGPU_SPLIT_PARTS");            // tuning: 2 (default), 4 or 8 parallel chains
         if (ek && (atoi(ek) == 4 || atoi(ek) == 8) && batch % atoi(ek) == 0) K = atoi(ek);
         for (int c = 0; c < K; c++) {
-            ffgpu_exec *ch = ffgpu_exec_create(net, batch / K, (flags & ~FFGPU_HOST_DETS) | FFGPU_INTERNAL_CHILD);
+            ffgpu_exec *ch = exec_create_on(dev, net, batch / K, (flags & ~FFGPU_HOST_DETS) | FFGPU_INTERNAL_CHILD);
             if (!ch) { ffgpu_exec_destroy(ex); return nullptr; }
             (void)hipFree(ch->d_dets); (void)hipFree(ch->d_full);
             ch->d_dets = ex->d_dets + (size_t)c * (batch / K);
@@ -817,6 +825,9 @@ extern "C" ffgpu_exec *ffgpu_exec_create(NET *net, int batch, int flags)
 extern "C" void ffgpu_exec_destroy(ffgpu_exec *ex)
 {
     if (!ex) return;
+    int cur_dev = ex->device;
+    (void)hipGetDevice(&cur_dev);
+    if (cur_dev != ex->device) (void)hipSetDevice(ex->device);      // (a node's executors live on other devices than the caller's)
     if (ex->last_stream) (void)hipStreamSynchronize(ex->last_stream);
     // a graph with a forked branch (the head branch) keeps ~its arena's worth of device memory if its exec is destroyed after
     // a sync of the launch stream alone (ROCm 7.0; tools/leak_check.py: +27 MB per create / forward / destroy cycle) --
@@ -843,6 +854,7 @@ extern "C" void ffgpu_exec_destroy(ffgpu_exec *ex)
     if (ex->side_stream) (void)hipStreamDestroy(ex->side_stream);
     if (ex->ev_fork) (void)hipEventDestroy(ex->ev_fork);
     if (ex->ev_join) (void)hipEventDestroy(ex->ev_join);
+    if (cur_dev != ex->device) (void)hipSetDevice(cur_dev);
     delete ex;
 }
 
@@ -1113,7 +1125,9 @@ extern "C" int ffgpu_exec_profile_steps(ffgpu_exec *ex, const float *d_frames, i
 }
 
 // -------------------------------------------------------------------------- C-ABI: net device state
-extern "C" void *ffgpu_netdev_create(NET *net)
+// device copy of the net's folded filter rows on `device` (-1: the calling thread's current device); upload == false leaves
+// it zeroed -- the other GPUs of a node receive the weights over RCCL (ffgpu_node.inc)
+static ffgpu_netdev *netdev_create_on(NET *net, int device, bool upload)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -1123,10 +1137,12 @@ extern "C" void *ffgpu_netdev_create(NET *net)
     }
     ffgpu_netdev *dev = new ffgpu_netdev();
     dev->net = net;
-    if (hipGetDevice(&dev->device) != hipSuccess) dev->device = 0;
+    if (device >= 0) { dev->device = device; if (hipSetDevice(device) != hipSuccess) { ffgpu_set_error("hipSetDevice(%d) failed", device); delete dev; return nullptr; } }
+    else if (hipGetDevice(&dev->device) != hipSuccess) dev->device = 0;
     dev->weight_bytes = sizeof(float) * (size_t)std::max(net->weight_size, 1);
     if (hipMalloc(&dev->d_weights, dev->weight_bytes) != hipSuccess ||
-        hipMemcpy(dev->d_weights, net->weight_buf, sizeof(float) * (size_t)net->weight_size, hipMemcpyHostToDevice) != hipSuccess) {
+        (upload ? hipMemcpy(dev->d_weights, net->weight_buf, sizeof(float) * (size_t)net->weight_size, hipMemcpyHostToDevice)
+                : hipMemset(dev->d_weights, 0, dev->weight_bytes)) != hipSuccess) {
         ffgpu_set_error("weight upload failed: %s", hipGetErrorString(hipGetLastError()));
         (void)hipFree(dev->d_weights);
         delete dev;
@@ -1134,6 +1150,8 @@ extern "C" void *ffgpu_netdev_create(NET *net)
     }
     return dev;
 }
+
+extern "C" void *ffgpu_netdev_create(NET *net) { return netdev_create_on(net, -1, true); }
 
 extern "C" void ffgpu_netdev_destroy(void *p)
 {
@@ -1212,6 +1230,8 @@ extern "C" int ffgpu_net_weights_commit(NET *net, void *stream)
     if (!stream) for (ffgpu_exec *ex : dev->execs) FFGPU_CHECK(hipStreamSynchronize(ex->own_stream));
     return 0;
 }
+
+#include "ffgpu_node.inc"
 
 // -------------------------------------------------------------------------- C-ABI: single conv on device tensors
 static void fill_desc(ConvDesc &d, const float *in, const float *filt, float *out, int batch,

@@ -151,6 +151,32 @@ int ffgpu_exec_profile(ffgpu_exec *ex, const float *d_frames, float us_by_kind[L
  * device time.  Returns the number of steps (<= cap) or a negative error. */
 int ffgpu_exec_profile_steps(ffgpu_exec *ex, const float *d_frames, int *layer_of, float *us, int cap);
 
+/* ---- all GPUs of one node from one C process (counterpart of calling net_forward once per frame) ------
+ * A batch of `global_batch` independent frames is cut into contiguous shards, one per device (ffgpu_shard_range); every
+ * device holds its own copy of the folded filter rows -- broadcast ONCE from rank 0 over RCCL (ncclBroadcast) inside
+ * ffgpu_node_create -- and runs the whole net on its shard (own executor, stream and HIP graph); per forward the shards'
+ * detection records are gathered on rank 0 (grouped ncclSend / ncclRecv over xGMI) and land in the caller's host buffer
+ * in global frame order.  No all-reduce, no activation exchange.  RCCL is loaded at run time (librccl.so.1) the first
+ * time a node is created without FFGPU_NODE_LOOPBACK; single-GPU users never load it. */
+typedef struct ffgpu_node ffgpu_node;
+#define FFGPU_NODE_LOOPBACK 1   /* node_flags: peer copies instead of RCCL; several ranks may share a device (tests) */
+
+/* frames [lo, hi) of `rank` out of `world`: sizes differ by at most one, earlier ranks take the extra */
+void        ffgpu_shard_range(int total, int rank, int world, int *lo, int *hi);
+/* devices: ndev device ordinals (rank 0 = the device `net` was loaded on) or NULL for that device and the next ndev - 1.
+ * exec_flags: FFGPU_* executor flags for the per-device executors (FFGPU_COMPAT_V6, FFGPU_NO_GRAPH, FFGPU_SPLIT2 ...). */
+ffgpu_node *ffgpu_node_create(NET *net, int ndev, const int *devices, int global_batch, int exec_flags, int node_flags);
+void        ffgpu_node_destroy(ffgpu_node *node);
+int         ffgpu_node_ndev(const ffgpu_node *node);
+int         ffgpu_node_shard(const ffgpu_node *node, int rank, int *lo, int *hi, int *device);
+int         ffgpu_node_set_scale(ffgpu_node *node, int s1, int s2);       /* as ffgpu_exec_set_scale, every rank */
+/* rank's input shard on ITS device, (hi - lo) x C x H x W fp32 frame-major, owned by the node: fill it there ... */
+float      *ffgpu_node_input_dev(ffgpu_node *node, int rank);
+/* ... then run: forward on every device, gather, records of all global_batch frames to host_out; returns when they are there */
+int         ffgpu_node_forward(ffgpu_node *node, ffgpu_frame_dets *host_out);
+/* or hand over the whole batch in host memory (global_batch x C x H x W fp32): shards are copied to their devices first */
+int         ffgpu_node_forward_host(ffgpu_node *node, const float *h_frames, ffgpu_frame_dets *host_out);
+
 /* ---- single operators on device tensors (CNHW, any batch) --------------- */
 /* Counterpart of groupconv (conv.h:4-7) without the host round trip.  d_in is
  * ic*batch planes of ih*iw, d_out oc*batch planes of oh*ow; d_filt as conv.h.

@@ -68,3 +68,26 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".c", ".h", ".hpp", ".hip", ".inc", "Makefile")):
                 txt = open(os.path.join(base, f), errors="replace").read()
                 assert "oracle" not in txt.lower() or f == "__init__.py" and False, os.path.join(base, f)
+
+
+def test_shard_range_c_equals_python(capi):
+    """ffgpu_shard_range (what the C node path cuts a batch with) == ffcnn_amd.dist.shard_range (the torchrun path);
+    shards are contiguous, cover the batch and differ by at most one frame"""
+    from ffcnn_amd import dist as ffdist
+    for total in (1, 2, 7, 32, 64, 255, 256, 257):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            sizes = []
+            for r in range(world):
+                lo, hi = capi.shard_range(total, r, world)
+                assert (lo, hi) == ffdist.shard_range(total, r, world)
+                assert lo == prev and hi >= lo
+                prev = hi
+                sizes.append(hi - lo)
+            assert prev == total and max(sizes) - min(sizes) <= 1
+
+
+def test_node_needs_a_net_with_device_state(capi):
+    import ctypes as C
+    assert not capi.lib().ffgpu_node_create(None, 1, None, 4, 0, 0)
+    assert "NULL net" in capi.last_error()

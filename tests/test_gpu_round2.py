@@ -387,3 +387,58 @@ def test_profile_fills_timeused(F, test_image, monkeypatch, capfd):
         n.set_input_image(bgr, w, h)
         n.forward()
         assert not any(n.n.timeused)
+
+
+# ------------------------------------------------------------------ C-ABI multi-GPU node (one process)
+def test_node_one_gpu_over_rccl_equals_executor(F, net, eight):
+    """ffgpu_node_* with ndev = 1 through the real RCCL path (communicator, broadcast, gather are set up and degenerate):
+    byte-identical records to a plain executor of the same batch"""
+    fr, runs = eight
+    with net.executor(8, F.FFGPU.CONCURRENT) as ex:
+        ex.set_scale(640, 320)
+        ex.forward_host(fr)
+        want = ex.read_dets()
+    with F.Node(net, 1, 8, exec_flags=F.FFGPU.CONCURRENT) as nd:
+        assert nd.shard(0)[:2] == (0, 8)
+        nd.set_scale(640, 320)
+        for _ in range(3):
+            got = nd.forward_host(fr)
+            assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("ranks,total", [(2, 8), (3, 8), (4, 7)])
+def test_node_multi_rank_loopback(F, net, eight, ranks, total):
+    """the multi-rank path on ONE device (FFGPU_NODE_LOOPBACK: peer copies instead of RCCL): ranks > 1 get zeroed weights
+    that only the broadcast fills, uneven contiguous shards, per-rank executors, gather offsets -- records of every frame
+    against the oracle, in global frame order"""
+    fr, runs = eight
+    with F.Node(net, ranks, total, exec_flags=0, node_flags=F.Node.LOOPBACK) as nd:
+        covered = []
+        for r in range(ranks):
+            lo, hi, dev = nd.shard(r)
+            assert (lo, hi) == F.shard_range(total, r, ranks)
+            covered += list(range(lo, hi))
+        assert covered == list(range(total))
+        for rep in range(2):
+            dets = nd.forward_host(fr[:total])
+            for f in range(total):
+                assert dets[f]["ncand"] == len(runs[f]["cand"])
+                boxes_match(dets[f]["box"][:dets[f]["count"]], runs[f]["boxes"], "rank layout %d/%d frame %d" % (ranks, total, f))
+    with pytest.raises(RuntimeError, match="used twice"):
+        F.Node(net, 2, 8, devices=[0, 0])                              # RCCL wants one rank per device
+
+
+def test_node_demo_in_c(tmp_path):
+    """ffcnn_node_demo: the plain-C host (net_load + ffgpu_node_*) prints the reference CLI's boxes for frame 0"""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "ffcnn_amd", "bin", "ffcnn_node_demo")
+    data = os.path.join(ROOT, "data")
+    out = subprocess.run([exe, "1", "8", "3", os.path.join(data, "test.bmp"), os.path.join(data, "yolo-fastest-1.1.cfg"),
+                          os.path.join(data, "yolo-fastest-1.1.weights")], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-400:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("score:")]
+    # net_320x320_v0 of tests/golden/boxes.json in the CLI's print format (ffcnn.c:586)
+    assert lines == ["score: 0.98, category:  0, rect: (195  99 278 371)", "score: 0.98, category: 18, rect: (403 138 593 326)",
+                     "score: 0.92, category: 16, rect: ( 82 267 202 347)"], out.stdout
+    assert "rank 0: device 0, frames [0, 8)" in out.stdout and "frames/s" in out.stdout
