@@ -466,14 +466,14 @@ static int plan(ffgpu_exec *ex)
         size_t tot = 0;
         for (Step &st : S) {
             if (st.kind == S_IRB) tot += ffgpu_irb_pack_floats(st.irb);
-            if (st.kind == S_CONV && !st.in_is_input) tot += ffgpu_pw_pack_floats(st.conv);
+            if (st.kind == S_CONV) tot += ffgpu_pw_pack_floats(st.conv);
         }
         if (tot) {
             if (hipMalloc(&ex->d_pack, tot * sizeof(float)) != hipSuccess) { ffgpu_set_error("hipMalloc(pack) failed"); return -1; }
             size_t off = 0;
             for (Step &st : S) {
                 if (st.kind == S_IRB) { st.irb.pk = ex->d_pack + off; off += ffgpu_irb_pack_floats(st.irb); }
-                if (st.kind == S_CONV && !st.in_is_input && ffgpu_pw_pack_floats(st.conv)) { st.conv.wpack = ex->d_pack + off; off += ffgpu_pw_pack_floats(st.conv); }
+                if (st.kind == S_CONV && ffgpu_pw_pack_floats(st.conv)) { st.conv.wpack = ex->d_pack + off; off += ffgpu_pw_pack_floats(st.conv); }
             }
         }
     }

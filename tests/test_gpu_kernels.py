@@ -178,6 +178,47 @@ def test_pw_gemm(env, orc, shape):
         check(got.reshape(oc, N, H, W)[:, 0], o, "pw_gemm %s frame 0 vs oracle" % (shape,))
 
 
+IGEMM_SHAPES = [  # (ic, oc, N, H, W, fs, stride, pad, act)
+    (16, 32, 2, 24, 20, 3, 1, 1, 2), (32, 64, 1, 13, 13, 3, 1, 1, 2), (64, 130, 3, 7, 9, 3, 1, 1, 0), (8, 21, 2, 12, 8, 5, 1, 2, 0),
+    (24, 48, 2, 17, 15, 3, 2, 1, 2), (12, 8, 1, 11, 11, 5, 2, 1, 1), (20, 10, 2, 9, 9, 3, 1, 0, 1), (128, 256, 1, 6, 4, 3, 1, 1, 2),
+    (40, 70, 1, 5, 5, 1, 1, 0, 3), (9, 5, 3, 3, 3, 2, 1, 0, 2), (256, 160, 4, 6, 4, 3, 1, 1, 2), (16, 16, 1, 1, 1, 3, 1, 1, 2),
+]
+
+
+@pytest.mark.parametrize("shape", IGEMM_SHAPES)
+def test_conv_igemm(env, orc, shape):
+    """dense KxK as implicit GEMM (k_conv_igemm: both tile shapes, ragged K / channels / pixels, odd pixel counts, stride 2,
+    pad 0, 5x5, 2x2, 1x1, sigmoid) against the generic kernel and, frame by frame, the oracle"""
+    capi, torch = env
+    ic, oc, N, H, W, fs, stride, pad, act = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f = make_filter(rng, oc, fs * fs * ic)
+    f[:, :fs * fs * ic] *= 3.0 / np.sqrt(fs * fs * ic)
+    assert capi.kernel_name(N, W, H, ic, 1, pad, stride, fs, oc, capi.FFGPU.K_IGEMM) == "conv_igemm"
+    got = run_dev(capi, torch, x, f, N, W, H, ic, 1, pad, stride, fs, oc, act, capi.FFGPU.K_IGEMM)
+    ref = run_dev(capi, torch, x, f, N, W, H, ic, 1, pad, stride, fs, oc, act, capi.FFGPU.K_GENERIC)
+    check(got, ref, "conv_igemm %s vs generic" % (shape,))
+    OH, OW = (H + 2 * pad - fs) // stride + 1, (W + 2 * pad - fs) // stride + 1
+    xf = x.reshape(ic, N, H, W)
+    for n in range(N):
+        o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, 1, pad, stride, fs, act)
+        check(got.reshape(oc, N, OH, OW)[:, n], o, "conv_igemm %s frame %d vs oracle" % (shape, n))
+
+
+def test_conv_igemm_frame_major_input_and_residual(env, orc):
+    """the strides the executor hands over for a first layer (frame-major batch input) and a fused shortcut"""
+    capi, torch = env
+    ic, oc, N, H, W = 16, 24, 3, 10, 14
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, (N, ic, H, W)).astype(np.float32)                   # frame-major
+    f = make_filter(rng, oc, 9 * ic)
+    ref = np.stack([orc.groupconv(x[n], f, 1, 1, 1, 3, 2) for n in range(N)], 1)   # (oc, N, H, W)
+    cn = np.ascontiguousarray(x.transpose(1, 0, 2, 3)).reshape(ic * N, H, W)
+    got = run_dev(capi, torch, cn, f, N, W, H, ic, 1, 1, 1, 3, oc, 2, capi.FFGPU.K_IGEMM)
+    check(got.reshape(oc, N, H, W), ref, "igemm CNHW")
+
+
 def test_unsupported_variant_fails_loudly(env):
     capi, torch = env
     x = torch.zeros((4, 7, 7), device="cuda")          # W % 4 != 0: the stream kernel must refuse

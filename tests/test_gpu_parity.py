@@ -484,6 +484,44 @@ def _write_random_weights(path, orc_net, seed):
             fp.write((rng.uniform(-1, 1, L.fn * K) * (1.6 / np.sqrt(K))).astype("<f4").tobytes())
 
 
+@pytest.mark.parametrize("batch", [1, 5])
+@pytest.mark.parametrize("flags", [1, 0])
+def test_tiny3_cfg_implicit_gemm(F, orc, tmp_path, flags, batch):
+    """tests/data/tiny3.cfg: a yolov3-tiny-shaped net (dense 3x3 stack, 1x1 bottlenecks, a dense 5x5, two heads through route +
+    upsample): every conv behind the first runs on the implicit-GEMM MFMA kernel -- every layer and the boxes against the oracle"""
+    from conftest import ROOT
+    cfg = os.path.join(ROOT, "tests", "data", "tiny3.cfg")
+    o = orc.Oracle(cfg=cfg, weights=None)
+    wpath = str(tmp_path / "tiny3.weights")
+    _write_random_weights(wpath, o, 7)
+    o.close()
+    o = orc.Oracle(cfg=cfg, weights=wpath)
+    rng = np.random.default_rng(11)
+    frames = rng.uniform(0, 1, (batch, 3, 64, 96)).astype(np.float32)
+    keep = F.FFGPU.KEEP_ALL | F.FFGPU.NO_FUSE if flags else 0
+    with F.Net(cfg, wpath) as n:
+        assert n.layer_num == o.nlayers == 22
+        for i in (2, 4, 6, 8, 10, 12, 19, 20):
+            L = n.layer(i)
+            assert F.kernel_name(batch, L.w, L.h, L.c, 1, L.pad, L.stride, L.fs, L.fn) == "conv_igemm", i
+        with n.executor(batch, keep) as ex:
+            ex.forward_host(frames)
+            dets = ex.read_dets()
+            for f in range(batch):
+                o.input[...] = frames[f]
+                o.n.s1, o.n.s2 = 1, 1
+                o.forward(0)
+                if keep:
+                    for i in range(o.nlayers):
+                        ref = o.layer_out(i)
+                        if ref is None:
+                            continue
+                        close(ex.read_layer(i, f), ref, "tiny3 frame %d layer %d" % (f, i))
+                assert dets[f]["ncand"] == len(o.candidates)
+                boxes_match(ex.boxes(f, dets), o.boxes, "tiny3 boxes frame %d" % f)
+    o.close()
+
+
 @pytest.mark.parametrize("flags", [1, 0])      # 1: KEEP_ALL | NO_FUSE with per-layer checks, 0: default fused graph executor
 def test_other_cfg_generic_path(F, orc, tmp_path, flags):
     """a cfg that is NOT yolo-fastest (tests/data/mini.cfg: grouped 3x3, dense 5x5 s2, unpadded 3x3, avgpool, relu,
