@@ -689,6 +689,17 @@ static void drop_graphs(ffgpu_exec *ex)                       // caller has sync
     ex->graphs.clear();
 }
 
+// The launch list is captured into its graph when the executor is created (the input pointer travels through the parameter
+// block, so no buffer has to be known): kernel choices, tile splits and packed-constant layouts -- which the FFGPU_* tuning
+// switches influence -- are thereby frozen together with the plan; a switch changed between ffgpu_exec_create and the first
+// forward cannot make a launch disagree with the constants packed for it.  (Eager FFGPU_NO_GRAPH executors re-read the
+// switches per forward: they are a debugging mode.)
+static int capture_at_create(ffgpu_exec *ex)
+{
+    if ((ex->flags & FFGPU_NO_GRAPH) || !graph_pointer_free(ex)) return 0;
+    return capture(ex, nullptr, &ex->graph1);
+}
+
 static int forward_on(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
 {
     ex->last_stream = s;
@@ -815,10 +826,12 @@ static ffgpu_exec *exec_create_on(ffgpu_netdev *dev, NET *net, int batch, int fl
                 ffgpu_set_error("split executor: stream / event creation failed"); ffgpu_exec_destroy(ex); return nullptr; }
         }
         { std::lock_guard<std::mutex> lk(dev->mu); dev->execs.push_back(ex); }
+        if (capture_at_create(ex)) { ffgpu_exec_destroy(ex); return nullptr; }
         return ex;
     }
     if (plan(ex) != 0 || repack(ex, ex->own_stream) != 0 || hipStreamSynchronize(ex->own_stream) != hipSuccess) { ffgpu_exec_destroy(ex); return nullptr; }
     { std::lock_guard<std::mutex> lk(dev->mu); dev->execs.push_back(ex); }
+    if (!as_child && capture_at_create(ex)) { ffgpu_exec_destroy(ex); return nullptr; }
     return ex;
 }
 

@@ -269,9 +269,14 @@ IRB_SHAPES = [  # (ic, ec, oc, stride, N, H, W, residual)
 
 
 @pytest.mark.parametrize("shape", IRB_SHAPES)
-def test_irb_fused_block(env, shape):
-    """fused expand->dw3x3->project(+shortcut) == three generic groupconv launches + add on the same tensors"""
+def test_irb_fused_block(env, shape, orc=None):
+    """fused expand->dw3x3->project(+shortcut) == three generic groupconv launches + add on the same tensors, and == the
+    ORACLE's three groupconv calls + shortcut per frame (conv-v0.c:7-31, ffcnn.c:418-423)"""
     capi, torch = env
+    if orc is None:
+        from oracle import orc as _orc
+        _orc.build()
+        orc = _orc
     ic, ec, oc, stride, N, H, W, use_res = shape
     rng = np.random.default_rng(hash(shape) & 0xffff)
     x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
@@ -288,7 +293,16 @@ def test_irb_fused_block(env, shape):
     capi.irb_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr() if use_res else None,
                  out.data_ptr(), N, W, H, ic, ec, oc, stride)
     torch.cuda.synchronize()
-    check(out.cpu().numpy(), ref, "irb %s" % (shape,))
+    got = out.cpu().numpy()
+    check(got, ref, "irb %s" % (shape,))
+    xf, rf, gf = x.reshape(ic, N, H, W), res.reshape(oc, N, OH, OW), got.reshape(oc, N, OH, OW)
+    for n in range(N):
+        o1 = orc.groupconv(np.ascontiguousarray(xf[:, n]), f1, 1, 0, 1, 1, 2)
+        o2 = orc.groupconv(o1, fd, ec, 1, stride, 3, 2)
+        o3 = orc.groupconv(o2, f2, 1, 0, 1, 1, 0)
+        if use_res:
+            o3 = orc.shortcut(o3, np.ascontiguousarray(rf[:, n]), 0)
+        check(gf[:, n], o3, "irb %s frame %d vs oracle" % (shape, n))
 
 
 @pytest.mark.parametrize("band", [0, 1, 3, 5, 16])
