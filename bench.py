@@ -230,6 +230,9 @@ def main():
     ap.add_argument("--gather-every", type=int, default=0,
                     help="multi-GPU: steps whose records travel in one RCCL gather (fewer, larger collectives); 0 = 64, "
                          "or less when --steps is small so that a short run still ships full groups")
+    ap.add_argument("--merge-steps", type=int, default=0,
+                    help="strong scaling: consecutive steps whose shards one launch processes together (0 = as many as make a "
+                         "launch of ~128 frames: a 32-frame shard alone leaves the small-plane kernels short of waves)")
     ap.add_argument("--global-batch", type=int, default=int(os.environ.get("FFCNN_BENCH_GLOBAL_BATCH", "0")),
                     help="strong scaling (BASELINE config[4]: 256): a step is this many frames in total, cut into contiguous "
                          "shards of global/N per GPU; 0 = weak scaling, 64 frames per GPU")
@@ -263,6 +266,15 @@ def main():
     else:
         lo, B = rank * FRAMES_PER_GPU, FRAMES_PER_GPU
     G = args.global_batch if strong else B * world
+    # Strong scaling shrinks the shard with N (256 / 8 = 32 frames), and a 32-frame launch runs at 152 k frames/s per GPU
+    # where a 64-frame one reaches 178 k and a 128-frame one 187 k (profiles/r02_b_batch_per_launch.txt): the last planes of the
+    # net are 10x10 pixels, a launch needs frames to fill 256 CUs.  Steps are independent, so a launch takes the shards of
+    # MS consecutive steps (MS x B frames, their records in step order): every step's boxes still reach rank 0 inside the
+    # timed region, the schedule of the same work is coarser.  Weak scaling (the default) keeps MS = 1.
+    MS = 1
+    if strong:
+        MS = args.merge_steps if args.merge_steps > 0 else max(1, 128 // B)
+    Bx = MS * B                                                 # frames per launch
     stream = torch.cuda.Stream()
     roof = roof_pw = None
     net = capi.Net()
@@ -292,7 +304,7 @@ def main():
     M = args.gather_every
     if M <= 0:                                                  # groups a short run can fill at least once
         M = 64
-        while M > S and 2 * M > max(args.steps, 2 * S):
+        while M > S and 2 * M > max(-(-args.steps // MS), 2 * S):
             M //= 2
     M = max(M, (S + 1) // 2)
     if gather_mode and (2 * M) % S:
@@ -301,7 +313,7 @@ def main():
     flags = (capi.FFGPU.HOST_DETS if host_dets else 0) | (capi.FFGPU.SPLIT2 if args.split else 0)
     if S >= 3:
         flags |= capi.FFGPU.CONCURRENT      # plan for throughput: several chains fill the device together
-    exs = [net.executor(B, flags) for _ in range(S)]
+    exs = [net.executor(Bx, flags) for _ in range(S)]
     streams = [stream] + [torch.cuda.Stream() for _ in range(S - 1)]
     ex = exs[0]
     model_bytes, model_flops = ex.work_model()
@@ -326,14 +338,15 @@ def main():
     # the steps take K distinct batches in turn (frame 0 is the test image in each of them, the rest differs): one batch used
     # over and over would sit in the 256 MB Infinity Cache and the first layer would never read HBM
     for k in range(K_in):
-        xk = torch.empty((B, 3, 320, 320), device="cuda")
-        for c0 in range(0, G, 64):                              # the global batch in chunks; keep what falls into [lo, lo + B)
-            cn = min(64, G - c0)
-            chunk = torch.rand((cn, 3, 320, 320), device="cuda", generator=g)
-            a, b = max(c0, lo), min(c0 + cn, lo + B)
-            if a < b:
-                xk[a - lo:b - lo] = chunk[a - c0:b - c0]
-            del chunk
+        xk = torch.empty((Bx, 3, 320, 320), device="cuda")      # the shards of MS consecutive steps behind each other
+        for q in range(MS):
+            for c0 in range(0, G, 64):                          # one global batch in chunks; keep what falls into [lo, lo + B)
+                cn = min(64, G - c0)
+                chunk = torch.rand((cn, 3, 320, 320), device="cuda", generator=g)
+                a, b = max(c0, lo), min(c0 + cn, lo + B)
+                if a < b:
+                    xk[q * B + a - lo:q * B + b - lo] = chunk[a - c0:b - c0]
+                del chunk
         if img is not None:
             xk[0] = img
         xs.append(xk)
@@ -347,8 +360,8 @@ def main():
     ring = torch.empty((2, M, dbytes), dtype=torch.uint8, device="cuda") if gather_mode else None
     # what travels is the COMPACT form of a step's records (ffgpu_pack_records on the side stream: 25 KB instead of 198 KB
     # per step at batch 64 -- the fixed-size records are almost all unused box slots), room for 16 boxes per frame on average
-    CAP = 16 * B
-    pbytes = capi.packed_records_bytes(B, CAP)
+    CAP = 16 * Bx
+    pbytes = capi.packed_records_bytes(Bx, CAP)
     cring = torch.empty((2, M, pbytes), dtype=torch.uint8, device="cuda") if gather_mode else None
     big = torch.empty((world, M * pbytes), dtype=torch.uint8, device="cuda") if (gather_mode and rank == 0) else None
     glist = list(big.unbind(0)) if big is not None else None
@@ -367,7 +380,7 @@ def main():
         with torch.cuda.stream(comm):
             for j in range(S):
                 comm.wait_event(ev_fwd[g][j])                   # every chain has written its slots of the group
-            capi.pack_records_dev(ring[g].data_ptr(), ns, B, B, CAP, cring[g].data_ptr(), comm.cuda_stream)
+            capi.pack_records_dev(ring[g].data_ptr(), ns, Bx, Bx, CAP, cring[g].data_ptr(), comm.cuda_stream)
             ffdist.gather_records(dist, cring[g].view(-1)[:nb], dst=0, out=[t[:nb] for t in glist] if glist is not None else None)
             if rank == 0:
                 host[g][:, :nb].copy_(big[:, :nb], non_blocking=True)   # one D2H copy for the whole job's records of the group
@@ -395,7 +408,7 @@ def main():
         if gather_mode:
             torch.cuda.synchronize()
             for j, e in enumerate(exs):                         # executor j's forward k is global step k * S + j
-                e.set_ring(ring.data_ptr() + j * dbytes, 2 * M // S, S * B)
+                e.set_ring(ring.data_ptr() + j * dbytes, 2 * M // S, S * Bx)
 
     def fence():
         torch.cuda.synchronize()
@@ -427,17 +440,18 @@ def main():
         roof_pw = pw_roofline(torch, capi, stream)
         torch.cuda.synchronize()
     # warm-up and timed steps are numbered from 0 each, so both start on a fresh group and end with a flush
+    nl_warm, nl = -(-args.warmup // MS), -(-args.steps // MS)    # launches (a launch = MS steps; a ragged last one still does MS)
     restart()
-    for i in range(args.warmup):
+    for i in range(nl_warm):
         step(i)
-    flush(args.warmup)
+    flush(nl_warm)
     fence()
     restart()
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(nl):
         step(i)
-    flush(args.steps)
+    flush(nl)
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -471,6 +485,7 @@ def main():
             "config": {"workload": ("yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[3])" if not strong else
                                     "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM, global batch %d in contiguous shards (BASELINE config[4])" % G),
                        "frames_per_gpu": B, "global_batch": G, "parallelism": "dp%d" % world,
+                       "steps_per_launch": MS, "frames_per_launch": Bx,
                        "input_sets": K_in,
                        "launches_per_step": ex.kernel_count, "arena_MB": round(ex.arena_bytes / 2**20, 1),
                        "executors": S, "pipelining": "%d executors on %d streams take the batches in turn%s" % (S, S, ", each split in two half-batch chains" if args.split else ""), "gather": ("RCCL gather of %d steps' records (packed: %d bytes per step and rank) + D2H on a side stream, overlapped with the next steps" % (M, pbytes)) if gather_mode else "records written to pinned host memory by the NMS kernel",
@@ -481,10 +496,10 @@ def main():
             # (each launch's inputs + outputs + filter rows once: ffgpu_exec_work_model) at the HBM peak, and the conv
             # stack's multiply-adds at the fp32 matrix peak.  Neither bounds the net tightly -- most launches are bound
             # by a wave's serial chain of MFMA + VALU issue -- but they are the honest denominators.
-            "roofline_net": {"fused_algorithmic_bytes_per_batch": int(model_bytes), "hbm_GBs": round(model_bytes / per_gpu_s / 1e9, 1),
-                             "hbm_frac": round(model_bytes / per_gpu_s / 1e9 / HBM_PEAK_GBS, 4),
-                             "flops_per_batch": int(model_flops), "TFLOPs": round(model_flops / per_gpu_s / 1e12, 2),
-                             "mfma_f32_frac": round(model_flops / per_gpu_s / 1e12 / FP32_MFMA_PEAK_TF, 4),
+            "roofline_net": {"fused_algorithmic_bytes_per_batch": int(model_bytes / MS), "hbm_GBs": round(model_bytes / MS / per_gpu_s / 1e9, 1),
+                             "hbm_frac": round(model_bytes / MS / per_gpu_s / 1e9 / HBM_PEAK_GBS, 4),
+                             "flops_per_batch": int(model_flops / MS), "TFLOPs": round(model_flops / MS / per_gpu_s / 1e12, 2),
+                             "mfma_f32_frac": round(model_flops / MS / per_gpu_s / 1e12 / FP32_MFMA_PEAK_TF, 4),
                              "batch": B},
         }
         if roof is not None:
@@ -502,9 +517,9 @@ def main():
         for i in range(nlat):
             exs[0].forward_dev(xs[i % K_in].data_ptr(), streams[0].cuda_stream)
         torch.cuda.synchronize()
-        out["roofline_net"]["single_chain_ms_per_batch"] = round((time.perf_counter() - t1) / nlat * 1e3, 4)
+        out["roofline_net"]["single_chain_ms_per_batch"] = round((time.perf_counter() - t1) / nlat / MS * 1e3, 4)
         gu = torch.Generator(device="cuda").manual_seed(1236)
-        us = [torch.randint(0, 256, (B, 320, 960), dtype=torch.uint8, device="cuda", generator=gu) for _ in range(K_in)]
+        us = [torch.randint(0, 256, (Bx, 320, 960), dtype=torch.uint8, device="cuda", generator=gu) for _ in range(K_in)]
         n8 = max(S, min(args.steps, 200) // S * S)
         for rep in range(2):
             torch.cuda.synchronize()
@@ -513,7 +528,7 @@ def main():
                 exs[i % S].forward_bgr_dev(us[i % K_in].data_ptr(), 320, 320, stream=streams[i % S].cuda_stream)
             torch.cuda.synchronize()
             t8 = time.perf_counter() - t1
-        out["config"]["u8_bgr_input"] = {"value": round(B * n8 / t8, 1), "unit": "frames/s", "steps": n8,
+        out["config"]["u8_bgr_input"] = {"value": round(Bx * n8 / t8, 1), "unit": "frames/s", "steps": n8,
                                          "what": "same job, %d u8 BGR 320x320 frames per step resident in HBM -> ffgpu_exec_forward_bgr_dev (batched net_input kernel + the net)" % B}
         del us
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
