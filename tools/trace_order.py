@@ -4,7 +4,7 @@ import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, start, end, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count from kernels order by start").fetchall()
 # last forward = after the last k_nms but one
-idx = [i for i, r in enumerate(rows) if r[0].startswith("k_nms")]
+idx = [i for i, r in enumerate(rows) if "k_nms" in r[0]]
 lo = idx[-2] + 1 if len(idx) >= 2 else 0
 hi = idx[-1] + 1
 t0 = rows[lo][1]
