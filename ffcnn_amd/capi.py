@@ -65,7 +65,8 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_read_boxes", "ffgpu_exec_cand_capacity", "ffgpu_exec_graph_captures",
            "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records",
            "ffgpu_shard_range", "ffgpu_node_create", "ffgpu_node_destroy", "ffgpu_node_ndev", "ffgpu_node_shard", "ffgpu_node_set_scale",
-           "ffgpu_node_input_dev", "ffgpu_node_forward", "ffgpu_node_forward_host"]
+           "ffgpu_node_input_dev", "ffgpu_node_input_slot_dev", "ffgpu_node_depth", "ffgpu_node_forward", "ffgpu_node_forward_host",
+           "ffgpu_node_submit", "ffgpu_node_wait"]
 # include/ffcnn_hip_diag.h (libffcnn_hip_diag.so: lab equipment, its own library)
 DIAG_EXPORTS = ["ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_pipe_probe2"]
 
@@ -154,6 +155,12 @@ def lib():
     L.ffgpu_node_set_scale.argtypes = [vp, i, i]
     L.ffgpu_node_input_dev.restype = vp
     L.ffgpu_node_input_dev.argtypes = [vp, i]
+    L.ffgpu_node_input_slot_dev.restype = vp
+    L.ffgpu_node_input_slot_dev.argtypes = [vp, i, i]
+    L.ffgpu_node_depth.argtypes = [vp]
+    L.ffgpu_node_submit.restype = C.c_long
+    L.ffgpu_node_submit.argtypes = [vp, f32p]
+    L.ffgpu_node_wait.argtypes = [vp, C.c_long, vp]
     L.ffgpu_node_forward.argtypes = [vp, vp]
     L.ffgpu_node_forward_host.argtypes = [vp, f32p, vp]
     _lib = L
@@ -442,6 +449,27 @@ def shard_range(total, rank, world):
 class Node:
     """ffgpu_node_*: one process, ndev GPUs (RCCL broadcast of the weights, gather of the records)"""
     LOOPBACK = 1
+
+    @staticmethod
+    def DEPTH(n):
+        return (n & 0xf) << 8
+
+    def submit(self, frames=None):
+        if frames is not None:
+            frames = np.ascontiguousarray(frames, np.float32)
+            assert frames.shape == (self.total,) + self.net.input_shape, frames.shape
+        t = lib().ffgpu_node_submit(self.h, frames.ctypes.data_as(f32p) if frames is not None else None)
+        if t < 0:
+            raise RuntimeError("ffgpu_node_submit failed: %s" % last_error())
+        return t
+
+    def wait(self, ticket):
+        out = np.zeros(self.total, DETS_DTYPE)
+        _check(lib().ffgpu_node_wait(self.h, ticket, out.ctypes.data), "ffgpu_node_wait")
+        return out
+
+    def input_slot_dev(self, rank, slot):
+        return lib().ffgpu_node_input_slot_dev(self.h, rank, slot)
 
     def __init__(self, net, ndev, global_batch, devices=None, exec_flags=0, node_flags=0):
         self.net, self.ndev, self.total = net, ndev, global_batch

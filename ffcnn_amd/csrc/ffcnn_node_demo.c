@@ -53,7 +53,8 @@ int main(int argc, char **argv)
         for (size_t row = 0; row < (size_t)l0->c * l0->h; row++)
             for (int x = 0; x < l0->w; x++)
                 frames[k * fl + row * l0->w + (size_t)((x + k) % l0->w)] = l0->data[row * l0->w + x];
-    ffgpu_node *node = ffgpu_node_create(net, ndev, NULL, batch, FFGPU_CONCURRENT, 0);
+    const int depth = 4;                                             /* steps in flight */
+    ffgpu_node *node = ffgpu_node_create(net, ndev, NULL, batch, FFGPU_CONCURRENT, FFGPU_NODE_DEPTH(depth));
     if (!node) { fprintf(stderr, "ffgpu_node_create failed: %s\n", ffgpu_last_error()); return 1; }
     ffgpu_node_set_scale(node, net->s1, net->s2);
     for (int r = 0; r < ndev; r++) {
@@ -61,11 +62,15 @@ int main(int argc, char **argv)
         ffgpu_node_shard(node, r, &lo, &hi, &dev);
         printf("rank %d: device %d, frames [%d, %d)\n", r, dev, lo, hi);
     }
-    if (ffgpu_node_forward_host(node, frames, dets)) { fprintf(stderr, "forward failed: %s\n", ffgpu_last_error()); return 1; }
+    for (int s = 0; s < depth; s++)                                  /* every slot's input buffers get the frames once */
+        if (ffgpu_node_forward_host(node, frames, dets)) { fprintf(stderr, "forward failed: %s\n", ffgpu_last_error()); return 1; }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (int i = 0; i < steps; i++)
-        if (ffgpu_node_forward(node, dets)) { fprintf(stderr, "forward failed: %s\n", ffgpu_last_error()); return 1; }
+    long ticket[8];
+    for (int i = 0; i < steps + depth; i++) {                        /* `depth` steps in flight: collect step i - depth, submit step i */
+        if (i >= depth && ffgpu_node_wait(node, ticket[i % depth], dets)) { fprintf(stderr, "wait failed: %s\n", ffgpu_last_error()); return 1; }
+        if (i < steps && (ticket[i % depth] = ffgpu_node_submit(node, NULL)) < 0) { fprintf(stderr, "submit failed: %s\n", ffgpu_last_error()); return 1; }
+    }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     const double dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     for (int i = 0; i < dets[0].count; i++) {

@@ -160,6 +160,8 @@ int ffgpu_exec_profile_steps(ffgpu_exec *ex, const float *d_frames, int *layer_o
  * time a node is created without FFGPU_NODE_LOOPBACK; single-GPU users never load it. */
 typedef struct ffgpu_node ffgpu_node;
 #define FFGPU_NODE_LOOPBACK 1   /* node_flags: peer copies instead of RCCL; several ranks may share a device (tests) */
+#define FFGPU_NODE_DEPTH(n) (((n) & 0xf) << 8)   /* node_flags: up to n (1..8) steps in flight: slot = step % n has its own executor, */
+                                /* compute stream and input buffer per device and its own gather / host buffers                   */
 
 /* frames [lo, hi) of `rank` out of `world`: sizes differ by at most one, earlier ranks take the extra */
 void        ffgpu_shard_range(int total, int rank, int world, int *lo, int *hi);
@@ -170,12 +172,20 @@ void        ffgpu_node_destroy(ffgpu_node *node);
 int         ffgpu_node_ndev(const ffgpu_node *node);
 int         ffgpu_node_shard(const ffgpu_node *node, int rank, int *lo, int *hi, int *device);
 int         ffgpu_node_set_scale(ffgpu_node *node, int s1, int s2);       /* as ffgpu_exec_set_scale, every rank */
-/* rank's input shard on ITS device, (hi - lo) x C x H x W fp32 frame-major, owned by the node: fill it there ... */
+int         ffgpu_node_depth(const ffgpu_node *node);
+/* rank's input shard on ITS device, (hi - lo) x C x H x W fp32 frame-major, owned by the node (the buffer the NEXT
+ * submitted step reads; ffgpu_node_input_slot_dev names a slot explicitly): fill it there ... */
 float      *ffgpu_node_input_dev(ffgpu_node *node, int rank);
+float      *ffgpu_node_input_slot_dev(ffgpu_node *node, int rank, int slot);
 /* ... then run: forward on every device, gather, records of all global_batch frames to host_out; returns when they are there */
 int         ffgpu_node_forward(ffgpu_node *node, ffgpu_frame_dets *host_out);
 /* or hand over the whole batch in host memory (global_batch x C x H x W fp32): shards are copied to their devices first */
 int         ffgpu_node_forward_host(ffgpu_node *node, const float *h_frames, ffgpu_frame_dets *host_out);
+/* Pipelined form: submit enqueues the next step on every device (h_frames may be NULL: the slot's input buffers are used as
+ * they are) plus its gather and returns the step's ticket (>= 0) without waiting; wait(ticket) blocks until that step's
+ * records are on the host and copies them.  At most `depth` tickets may be outstanding. */
+long        ffgpu_node_submit(ffgpu_node *node, const float *h_frames);
+int         ffgpu_node_wait(ffgpu_node *node, long ticket, ffgpu_frame_dets *host_out);
 
 /* ---- single operators on device tensors (CNHW, any batch) --------------- */
 /* Counterpart of groupconv (conv.h:4-7) without the host round trip.  d_in is

@@ -428,6 +428,29 @@ def test_node_multi_rank_loopback(F, net, eight, ranks, total):
         F.Node(net, 2, 8, devices=[0, 0])                              # RCCL wants one rank per device
 
 
+def test_node_pipelined_steps(F, net, eight):
+    """FFGPU_NODE_DEPTH(3): three steps in flight (own executor / stream / buffers per slot), submitted with different frames
+    and collected in order; a fourth submit without a wait is refused"""
+    fr, runs = eight
+    with F.Node(net, 2, 6, node_flags=F.Node.LOOPBACK | F.Node.DEPTH(3)) as nd:
+        assert F.lib().ffgpu_node_depth(nd.h) == 3
+        batches = [fr[[(k + j) % 8 for j in range(6)]] for k in range(7)]
+        tickets = []
+        for k, b in enumerate(batches):
+            if len(tickets) == 3:
+                t = tickets.pop(0)
+                dets = nd.wait(t)
+                for f in range(6):
+                    boxes_match(dets[f]["box"][:dets[f]["count"]], runs[(t + f) % 8]["boxes"], "step %d frame %d" % (t, f))
+            tickets.append(nd.submit(b))
+        with pytest.raises(RuntimeError, match="has not been collected"):
+            nd.submit(batches[0])
+        for t in tickets:
+            dets = nd.wait(t)
+            for f in range(6):
+                boxes_match(dets[f]["box"][:dets[f]["count"]], runs[(t + f) % 8]["boxes"], "step %d frame %d" % (t, f))
+
+
 def test_node_demo_in_c(tmp_path):
     """ffcnn_node_demo: the plain-C host (net_load + ffgpu_node_*) prints the reference CLI's boxes for frame 0"""
     import subprocess
