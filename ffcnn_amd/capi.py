@@ -63,7 +63,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_kernel_count", "ffgpu_exec_work_model", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
            "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_set_ring", "ffgpu_exec_set_ring_strided", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
            "ffgpu_exec_read_boxes", "ffgpu_exec_cand_capacity", "ffgpu_exec_graph_captures",
-           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records",
+           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_dwpw_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records",
            "ffgpu_shard_range", "ffgpu_node_create", "ffgpu_node_destroy", "ffgpu_node_ndev", "ffgpu_node_shard", "ffgpu_node_set_scale",
            "ffgpu_node_input_dev", "ffgpu_node_input_slot_dev", "ffgpu_node_depth", "ffgpu_node_forward", "ffgpu_node_forward_host",
            "ffgpu_node_submit", "ffgpu_node_wait"]
@@ -141,6 +141,8 @@ def lib():
     L.ffgpu_exec_read_boxes.argtypes = [vp, i, vp, i]
     L.ffgpu_exec_cand_capacity.argtypes = [vp]
     L.ffgpu_exec_graph_captures.argtypes = [vp]
+    L.ffgpu_dwpw_dev.restype = C.c_float
+    L.ffgpu_dwpw_dev.argtypes = [vp] * 4 + [i] * 10 + [vp]
     L.ffgpu_packed_records_bytes.restype = C.c_size_t
     L.ffgpu_packed_records_bytes.argtypes = [i, i]
     L.ffgpu_pack_records.restype = i
@@ -540,6 +542,14 @@ def pack_records_dev(d_records, nslots, slot_stride_records, batch, cap, d_out, 
 
 def kernel_name(batch, iw, ih, ic, groups, pad, stride, fs, fn, variant=0):
     return lib().ffgpu_groupconv_kernel_name(batch, iw, ih, ic, groups, pad, stride, fs, fn, variant).decode()
+
+
+def dwpw_dev(d_in, d_wd, d_wp, d_out, batch, iw, ih, c, oc, fs, actd=2, actp=0, warmup=0, iters=0, stream=None):
+    """fused depthwise KxK (s1, same padding) -> pointwise 1x1; returns us per launch when iters > 0"""
+    us = lib().ffgpu_dwpw_dev(d_in, d_wd, d_wp, d_out, batch, iw, ih, c, oc, fs, actd, actp, warmup, iters, stream)
+    if us < 0:
+        raise RuntimeError("ffgpu_dwpw_dev failed: %s" % last_error())
+    return us
 
 
 def irb_dev(d_in, d_w1, d_wd, d_w2, d_res, d_out, batch, iw, ih, ic, ec, oc, stride, act1=2, actd=2, act2=0, res_act=0,

@@ -56,6 +56,12 @@ int    ffgpu_launch_irb(const IrbDesc &d, hipStream_t s);
 bool   ffgpu_front_ok(const ConvDesc &c, const IrbDesc &d);      // first layer (3x3 s2, 3 -> 8) + thin block as one streaming kernel
 int    ffgpu_launch_front(const ConvDesc &c, const IrbDesc &d, hipStream_t s);
 
+// depthwise K x K (stride 1, same padding) + pointwise 1 x 1 as one launch (ffgpu_dwpw.inc); dw.out == pw.in is never written
+bool   ffgpu_dwpw_ok(const ConvDesc &dw, const ConvDesc &pw);
+size_t ffgpu_dwpw_pack_floats(const ConvDesc &dw, const ConvDesc &pw);
+int    ffgpu_dwpw_pack(const ConvDesc &dw, const ConvDesc &pw, float *pk, hipStream_t s);
+int    ffgpu_launch_dwpw(const ConvDesc &dw, const ConvDesc &pw, const float *wpack, hipStream_t s);
+
 size_t ffgpu_pw_pack_floats(const ConvDesc &d);
 int    ffgpu_pw_pack(const ConvDesc &d, float *pk, hipStream_t s);
 

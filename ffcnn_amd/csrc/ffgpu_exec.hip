@@ -61,13 +61,14 @@ extern "C" int ffgpu_set_device(int ordinal)
 // --------------------------------------------------------------------------
 #define FFGPU_INTERNAL_CHILD 0x40000000   /* executor flag used only inside this file: a half of a split executor */
 
-enum StepKind { S_CONV, S_POOL, S_UPSAMPLE, S_ADD, S_COPY, S_YOLO, S_NMS, S_CLEAR, S_TOCNHW, S_IRB, S_FRONT };
+enum StepKind { S_CONV, S_POOL, S_UPSAMPLE, S_ADD, S_COPY, S_YOLO, S_NMS, S_CLEAR, S_TOCNHW, S_IRB, S_FRONT, S_DWPW };
 
 struct Step {
     StepKind kind;
     int      layer;          // reference layer index this step belongs to (-1: none)
     int      ltype;          // LAYER_TYPE_* for profiling
-    ConvDesc conv;           // S_CONV (in == nullptr: patched to the batch input at launch)
+    ConvDesc conv;           // S_CONV (in == nullptr: patched to the batch input at launch); S_DWPW: the depthwise layer
+    ConvDesc conv2;          // S_DWPW: the pointwise layer behind it
     bool     in_is_input;    // S_CONV / S_POOL / S_UPSAMPLE / S_TOCNHW read the batch input
     const float *a, *b;      // generic sources
     float   *out;
@@ -225,6 +226,32 @@ static int plan(ffgpu_exec *ex)
             p0 += 2;
         }
     }
+    // pass 1c (opt-in, FFGPU_DWPW=1): depthwise K x K (stride 1) -> 1x1 pairs that no fused block claimed (the heads' 5x5 + 1x1
+    // of yolo-fastest) become one launch (ffgpu_dwpw.inc); the depthwise tensor is never materialised.  MEASURED (r02,
+    // tools/dwpw_bench.py): correct but SLOWER than the two launches it replaces -- 61 vs 8 + 15 us on 20x20x120 at batch 64
+    // (one workgroup per CU, a barrier chain of 15 short depthwise / MFMA phases with one wave per SIMD; 147.5 k frames/s
+    // end to end against 182.7 k) -- so the planner leaves the pairs alone unless asked.
+    auto layer_desc = [&](int i) {
+        ConvDesc d{};
+        const LAYER &a = ll[i], &b = ll[i + 1];
+        d.N = N; d.iw = a.w; d.ih = a.h; d.ic = a.c; d.ow = b.w; d.oh = b.h; d.oc = b.c;
+        d.fs = a.fs; d.stride = a.stride; d.pad = a.pad; d.groups = a.groups; d.act = a.activation;
+        d.flags = ex->flags & FFGPU_COMPAT_V6;
+        d.in_cs = (long)N * a.w * a.h; d.in_ns = (long)a.w * a.h;
+        d.out_cs = (long)N * b.w * b.h; d.out_ns = (long)b.w * b.h;
+        return d;
+    };
+    std::vector<int> dwpw_tail(L, -1);          // layer p+1 -> p
+    if (fuse && getenv("FFGPU_DWPW") && atoi(getenv("FFGPU_DWPW"))) {
+        for (int p0 = 0; p0 + 1 < L; p0++) {
+            if (ll[p0].type != LAYER_TYPE_CONV || ll[p0 + 1].type != LAYER_TYPE_CONV) continue;
+            if (canon[p0] != p0 || canon[p0 + 1] != p0 + 1 || nuses[p0] != 1 || fused_into[p0] >= 0 || fused_into[p0 + 1] >= 0 || src_tensor(p0 - 1) < 0) continue;
+            if (!ffgpu_dwpw_ok(layer_desc(p0), layer_desc(p0 + 1))) continue;
+            dwpw_tail[p0 + 1] = p0;
+            canon[p0] = -3;
+            p0++;
+        }
+    }
     for (int i = 0; i < L; i++) if (canon[i] == i) { T[i].used = true; T[i].size = out_floats(i); }
     ex->readable.assign(L, 0);
     for (int i = 0; i < L; i++) {
@@ -260,6 +287,7 @@ static int plan(ffgpu_exec *ex)
         if (ll[i].type != LAYER_TYPE_ROUTE) touch(src_tensor(i - 1), i);                                  // chain input read at i
         for (int k = 0; k < ll[i].depend_num; k++) touch(src_tensor(ll[i].depend_list[k]), i);
         if (irb_tail[i] >= 0) touch(src_tensor(irb_tail[i] - 1), i);
+        if (dwpw_tail[i] >= 0) touch(src_tensor(dwpw_tail[i] - 1), i);
         if (irb_tail[i] >= 0 && fused_into[i] >= 0) touch(src_tensor(ll[fused_into[i]].depend_list[0]), i);
     }
     for (int t = 0; t < L; t++) {
@@ -290,7 +318,7 @@ static int plan(ffgpu_exec *ex)
             for (int i = y + 1; i < L && ok; i++)
                 for (int k = 0; k < ll[i].depend_num; k++) if (ll[i].depend_list[k] > r && ll[i].depend_list[k] <= y) ok = false;
             // nothing inside (r, y] may be a fused block straddling the fork (its first layer must be > r)
-            for (int i = r + 1; i <= y && ok; i++) if (irb_tail[i] >= 0 && irb_tail[i] <= r) ok = false;
+            for (int i = r + 1; i <= y && ok; i++) if ((irb_tail[i] >= 0 && irb_tail[i] <= r) || (dwpw_tail[i] >= 0 && dwpw_tail[i] <= r)) ok = false;
             if (fused_into[r] > r) ok = false;       // the fork tensor's producer was absorbed by a later shortcut
             if (!ok) continue;
             ex->side_lo = r + 1; ex->side_hi = y;
@@ -299,6 +327,7 @@ static int plan(ffgpu_exec *ex)
                 if (ll[i].type != LAYER_TYPE_ROUTE && src_tensor(i - 1) >= 0) T[src_tensor(i - 1)].last = L + 1;
                 for (int k = 0; k < ll[i].depend_num; k++) if (src_tensor(ll[i].depend_list[k]) >= 0) T[src_tensor(ll[i].depend_list[k])].last = L + 1;
                 if (irb_tail[i] >= 0 && src_tensor(irb_tail[i] - 1) >= 0) T[src_tensor(irb_tail[i] - 1)].last = L + 1;
+                if (dwpw_tail[i] >= 0 && src_tensor(dwpw_tail[i] - 1) >= 0) T[src_tensor(dwpw_tail[i] - 1)].last = L + 1;
             }
             for (int t = 0; t < L; t++) {
                 if (!T[t].used || T[t].parent < 0) continue;
@@ -372,6 +401,17 @@ static int plan(ffgpu_exec *ex)
                     d.residual = tensor_ptr(ex, src_tensor(sc.depend_list[0]));
                     d.res_act = sc.activation;
                 }
+                S.push_back(st);
+                break;
+            }
+            if (dwpw_tail[i] >= 0) {                                // depthwise (p0) + this pointwise layer: one launch
+                const int p0 = dwpw_tail[i];
+                st.kind = S_DWPW;
+                st.conv = layer_desc(p0); st.conv2 = layer_desc(i);
+                st.conv.in = tensor_ptr(ex, src_tensor(p0 - 1));
+                st.conv.filt = ex->dev->d_weights + (ll[p0].filter - net->weight_buf);
+                st.conv2.filt = ex->dev->d_weights + (a.filter - net->weight_buf);
+                st.conv2.out = tensor_ptr(ex, canon[i]);
                 S.push_back(st);
                 break;
             }
@@ -467,12 +507,14 @@ static int plan(ffgpu_exec *ex)
         for (Step &st : S) {
             if (st.kind == S_IRB) tot += ffgpu_irb_pack_floats(st.irb);
             if (st.kind == S_CONV) tot += ffgpu_pw_pack_floats(st.conv);
+            if (st.kind == S_DWPW) tot += ffgpu_dwpw_pack_floats(st.conv, st.conv2);
         }
         if (tot) {
             if (hipMalloc(&ex->d_pack, tot * sizeof(float)) != hipSuccess) { ffgpu_set_error("hipMalloc(pack) failed"); return -1; }
             size_t off = 0;
             for (Step &st : S) {
                 if (st.kind == S_IRB) { st.irb.pk = ex->d_pack + off; off += ffgpu_irb_pack_floats(st.irb); }
+                if (st.kind == S_DWPW) { st.conv2.wpack = ex->d_pack + off; off += ffgpu_dwpw_pack_floats(st.conv, st.conv2); }
                 if (st.kind == S_CONV && ffgpu_pw_pack_floats(st.conv)) { st.conv.wpack = ex->d_pack + off; off += ffgpu_pw_pack_floats(st.conv); }
             }
         }
@@ -518,6 +560,7 @@ static int repack(ffgpu_exec *ex, hipStream_t s)
 {
     for (const Step &st : ex->steps) {
         if (st.kind == S_IRB && ffgpu_irb_pack(st.irb, const_cast<float *>(st.irb.pk), s)) return -1;
+        if (st.kind == S_DWPW && ffgpu_dwpw_pack(st.conv, st.conv2, const_cast<float *>(st.conv2.wpack), s)) return -1;
         if (st.kind == S_CONV && st.conv.wpack && ffgpu_pw_pack(st.conv, const_cast<float *>(st.conv.wpack), s)) return -1;
     }
     return 0;
@@ -573,6 +616,8 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
         return 0; }
     case S_IRB:
         return ffgpu_launch_irb(st.irb, s);
+    case S_DWPW:
+        return ffgpu_launch_dwpw(st.conv, st.conv2, st.conv2.wpack, s);
     case S_FRONT: {
         ConvDesc d = st.conv;
         if (st.in_is_input && !d.in_ind) d.in = d_frames;
@@ -798,7 +843,10 @@ static ffgpu_exec *exec_create_on(ffgpu_netdev *dev, NET *net, int batch, int fl
            && hipMalloc(&ex->d_ncand, sizeof(int) * (size_t)batch) == hipSuccess && hipMemset(ex->d_ncand, 0, sizeof(int) * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_ringctr, sizeof(int)) == hipSuccess && hipMemset(ex->d_ringctr, 0, sizeof(int)) == hipSuccess
-           && hipMemset(ex->d_dets, 0, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess;
+           && hipMemset(ex->d_dets, 0, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess
+           // hipMemset of device memory is asynchronous on the NULL stream, and every stream this executor works on is
+           // non-blocking (not ordered with it): wait here, or a late memset may clear counters a forward has begun to use
+           && hipStreamSynchronize(nullptr) == hipSuccess;
     if (ok && (flags & FFGPU_HOST_DETS)) {
         ok = hipHostMalloc(&ex->h_dets, sizeof(ffgpu_frame_dets) * (size_t)batch, hipHostMallocMapped) == hipSuccess
           && hipHostGetDevicePointer((void **)&ex->h_dets_dev, ex->h_dets, 0) == hipSuccess;
@@ -898,6 +946,8 @@ extern "C" int ffgpu_exec_work_model(const ffgpu_exec *ex, double *hbm_bytes, do
                 by += 4.0 * (N * d.ic * d.ih * d.iw + N * d.oc * d.oh * d.ow * (d.residual ? 2 : 1) + rows(d)); break; }
             case S_IRB: { const IrbDesc &d = st.irb;
                 by += 4.0 * (N * d.ic * d.H * d.W + N * d.oc * d.OH * d.OW * (d.residual ? 2 : 1) + (double)d.ec * (d.ic + 4 + 16) + (double)d.oc * (d.ec + 4)); break; }
+            case S_DWPW: { const ConvDesc &a = st.conv, &b = st.conv2;
+                by += 4.0 * (N * a.ic * a.ih * a.iw + N * b.oc * b.oh * b.ow + rows(a) + rows(b)); break; }
             case S_FRONT: { const ConvDesc &c = st.conv; const IrbDesc &d = st.irb;
                 by += 4.0 * (N * c.ic * c.ih * c.iw + N * d.oc * d.OH * d.OW + rows(c)); break; }
             case S_POOL: { const int np = 1 + (st.fs2[0] != 0) + (st.fs2[1] != 0);
@@ -988,6 +1038,7 @@ extern "C" int ffgpu_exec_set_ring_strided(ffgpu_exec *ex, void *dev_ring, int s
         ch->ring = dev_ring ? ex->ring + (size_t)c * ch->N : nullptr; ch->ring_slots = ex->ring_slots; ch->ring_stride = slot_records;
         FFGPU_CHECK(hipMemset(ch->d_ringctr, 0, sizeof(int)));
     }
+    FFGPU_CHECK(hipStreamSynchronize(nullptr));                  // (the memsets above run on the NULL stream; forwards do not)
     return 0;
 }
 
@@ -1155,7 +1206,9 @@ static ffgpu_netdev *netdev_create_on(NET *net, int device, bool upload)
     dev->weight_bytes = sizeof(float) * (size_t)std::max(net->weight_size, 1);
     if (hipMalloc(&dev->d_weights, dev->weight_bytes) != hipSuccess ||
         (upload ? hipMemcpy(dev->d_weights, net->weight_buf, sizeof(float) * (size_t)net->weight_size, hipMemcpyHostToDevice)
-                : hipMemset(dev->d_weights, 0, dev->weight_bytes)) != hipSuccess) {
+                : hipMemset(dev->d_weights, 0, dev->weight_bytes)) != hipSuccess ||
+        hipStreamSynchronize(nullptr) != hipSuccess) {                // (the memset is asynchronous on the NULL stream: a broadcast on
+                                                                      //  another stream must not be overtaken by it)
         ffgpu_set_error("weight upload failed: %s", hipGetErrorString(hipGetLastError()));
         (void)hipFree(dev->d_weights);
         delete dev;
@@ -1329,6 +1382,39 @@ extern "C" float ffgpu_irb_dev(const float *d_in, const float *d_w1, const float
         for (int i = 0; i < warmup && !rc; i++) rc = ffgpu_launch_irb(d, s);
         (void)hipEventRecord(e0, s);
         for (int i = 0; i < iters && !rc; i++) rc = ffgpu_launch_irb(d, s);
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        us = ms * 1000.f / iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(pk);
+    return rc ? -1.f : us;
+}
+
+// depthwise K x K (stride 1, same padding) + pointwise 1x1 in one launch: two consecutive groupconv calls of the reference;
+// d_wd / d_wp are the two layers' filter rows (conv.h layout).  iters > 0: mean microseconds per launch instead of 0.
+extern "C" float ffgpu_dwpw_dev(const float *d_in, const float *d_wd, const float *d_wp, float *d_out, int batch, int iw, int ih,
+                                int c, int oc, int fs, int actd, int actp, int warmup, int iters, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    ConvDesc dw, pw;
+    fill_desc(dw, d_in, d_wd, nullptr, batch, iw, ih, c, c, fs / 2, 1, fs, iw, ih, c, actd, 0);
+    fill_desc(pw, nullptr, d_wp, d_out, batch, iw, ih, c, 1, 0, 1, 1, iw, ih, oc, actp, 0);
+    if (!d_in || !d_wd || !d_wp || !d_out || !ffgpu_dwpw_ok(dw, pw)) { ffgpu_set_error("dwpw_dev: unsupported layer pair"); return -1.f; }
+    float *pk = nullptr;
+    if (hipMalloc(&pk, ffgpu_dwpw_pack_floats(dw, pw) * sizeof(float)) != hipSuccess) { ffgpu_set_error("dwpw_dev: hipMalloc failed"); return -1.f; }
+    float us = 0.f;
+    int rc = ffgpu_dwpw_pack(dw, pw, pk, s);
+    if (!rc && iters <= 0) rc = ffgpu_launch_dwpw(dw, pw, pk, s);
+    if (!rc && iters > 0) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        for (int i = 0; i < warmup && !rc; i++) rc = ffgpu_launch_dwpw(dw, pw, pk, s);
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters && !rc; i++) rc = ffgpu_launch_dwpw(dw, pw, pk, s);
         (void)hipEventRecord(e1, s);
         (void)hipEventSynchronize(e1);
         float ms = 0.f;

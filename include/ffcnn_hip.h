@@ -229,6 +229,12 @@ float ffgpu_irb_dev(const float *d_in, const float *d_w1, const float *d_wd, con
                     const float *d_res, float *d_out, int batch, int iw, int ih, int ic, int ec, int oc,
                     int stride, int act1, int actd, int act2, int res_act, int warmup, int iters, void *stream);
 
+/* Fused pair: depthwise K x K (K = 3 | 5, stride 1, pad K / 2) -> pointwise 1x1, i.e. two consecutive groupconv calls of the
+ * reference in one kernel (the depthwise tensor never leaves the CU).  CNHW device tensors; d_wd / d_wp are the two layers'
+ * filter rows (conv.h layout).  iters > 0: returns mean microseconds per launch (HIP events on `stream`) instead of 0. */
+float ffgpu_dwpw_dev(const float *d_in, const float *d_wd, const float *d_wp, float *d_out, int batch, int iw, int ih,
+                     int c, int oc, int fs, int actd, int actp, int warmup, int iters, void *stream);
+
 /* ---- compact records for the multi-GPU gather ("fixed-size detection records to rank 0"): the
  * `batch` records of each of `nslots` steps (slot s starts at record s * slot_stride_records of d_records, e.g. a ring
  * set with ffgpu_exec_set_ring) are packed into nslots blocks of ffgpu_packed_records_bytes(batch, cap) bytes:

@@ -219,6 +219,35 @@ def test_conv_igemm_frame_major_input_and_residual(env, orc):
     check(got.reshape(oc, N, H, W), ref, "igemm CNHW")
 
 
+DWPW_SHAPES = [  # (C, OC, N, H, W, fs, actd, actp)
+    (120, 120, 3, 20, 20, 5, 2, 0), (96, 96, 2, 10, 10, 5, 2, 0), (16, 24, 2, 13, 7, 3, 2, 2), (20, 100, 1, 9, 33, 5, 1, 0),
+    (8, 8, 1, 4, 4, 3, 0, 0), (40, 17, 2, 40, 40, 5, 2, 1), (12, 20, 1, 6, 6, 3, 2, 0), (30, 128, 1, 17, 5, 5, 2, 0), (4, 4, 5, 4, 64, 3, 2, 0),
+]
+
+
+@pytest.mark.parametrize("shape", DWPW_SHAPES)
+def test_dwpw_fused_pair(env, orc, shape):
+    """depthwise KxK + pointwise 1x1 in one kernel (k_dwpw: the heads' pairs of yolo-fastest and ragged relatives: channel counts
+    off the 8 / 16 grids, planes that do not divide into tiles, one-tile and many-tile planes) against the oracle's two
+    groupconv calls per frame"""
+    capi, torch = env
+    C, OC, N, H, W, fs, actd, actp = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (C * N, H, W)).astype(np.float32)
+    fd, fp = make_filter(rng, C, fs * fs), make_filter(rng, OC, C)
+    fp[:, :C] *= 4.0 / np.sqrt(C)
+    t = [torch.from_numpy(a).cuda() for a in (x, fd, fp)]
+    out = torch.full((OC * N, H, W), float("nan"), device="cuda")
+    capi.dwpw_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), out.data_ptr(), N, W, H, C, OC, fs, actd, actp)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(OC, N, H, W)
+    xf = x.reshape(C, N, H, W)
+    for n in range(N):
+        o1 = orc.groupconv(np.ascontiguousarray(xf[:, n]), fd, C, fs // 2, 1, fs, actd)
+        o2 = orc.groupconv(o1, fp, 1, 0, 1, 1, actp)
+        check(got[:, n], o2, "dwpw %s frame %d vs oracle" % (shape, n))
+
+
 def test_unsupported_variant_fails_loudly(env):
     capi, torch = env
     x = torch.zeros((4, 7, 7), device="cuda")          # W % 4 != 0: the stream kernel must refuse

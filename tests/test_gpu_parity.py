@@ -484,6 +484,24 @@ def _write_random_weights(path, orc_net, seed):
             fp.write((rng.uniform(-1, 1, L.fn * K) * (1.6 / np.sqrt(K))).astype("<f4").tobytes())
 
 
+def test_dwpw_plan_opt_in(F, net, frames, oracle_runs, monkeypatch):
+    """FFGPU_DWPW=1: the heads' depthwise 5x5 + pointwise pairs as one launch each (k_dwpw; off by default: measured slower):
+    4 launches fewer, same activations behind the pairs, same records"""
+    with net.executor(4, F.FFGPU.KEEP_ALL) as ex:
+        base = ex.kernel_count
+    monkeypatch.setenv("FFGPU_DWPW", "1")
+    with net.executor(4, F.FFGPU.KEEP_ALL) as ex:
+        assert ex.kernel_count == base - 4
+        ex.forward_host(frames)
+        with pytest.raises(RuntimeError, match="not materialised"):
+            ex.read_layer(125, 0)
+        dets = ex.read_dets()
+        for f in range(4):
+            for i in (117, 119, 120, 126, 128, 129):
+                close(ex.read_layer(i, f), oracle_runs[f]["acts"][i], "dwpw plan: frame %d layer %d" % (f, i))
+            boxes_match(ex.boxes(f, dets), oracle_runs[f]["boxes"], "dwpw plan boxes frame %d" % f)
+
+
 @pytest.mark.parametrize("batch", [1, 5])
 @pytest.mark.parametrize("flags", [1, 0])
 def test_tiny3_cfg_implicit_gemm(F, orc, tmp_path, flags, batch):

@@ -422,7 +422,7 @@ def test_node_multi_rank_loopback(F, net, eight, ranks, total):
         for rep in range(2):
             dets = nd.forward_host(fr[:total])
             for f in range(total):
-                assert dets[f]["ncand"] == len(runs[f]["cand"])
+                assert dets[f]["ncand"] == len(runs[f]["cand"]), "rep %d frame %d: ncand %s" % (rep, f, [int(v) for v in dets["ncand"]])
                 boxes_match(dets[f]["box"][:dets[f]["count"]], runs[f]["boxes"], "rank layout %d/%d frame %d" % (ranks, total, f))
     with pytest.raises(RuntimeError, match="used twice"):
         F.Node(net, 2, 8, devices=[0, 0])                              # RCCL wants one rank per device
