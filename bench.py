@@ -207,7 +207,20 @@ def pw_roofline(torch, capi, stream):
                                  warmup=4, iters=50, stream=stream.cuda_stream)
     flops = 2.0 * oc * ic * N * H * W
     tfs = flops / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "kernel": capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc), "achieved": round(tfs, 2),
+    # beside it (NOT the product default, never used by the net's timed steps): the opt-in bf16-input variant of the same layer
+    # (FFGPU_BF16_PW; its own tolerance in tests/test_gpu_kernels.py::test_pw_bf16) -- on the bf16 matrix cores the layer is
+    # HBM-bound: 315 MB of fp32 input + output per launch
+    bf = None
+    try:
+        us_bf = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2, flags=capi.FFGPU.BF16_PW,
+                                        variant=capi.FFGPU.K_PW_BF16, warmup=4, iters=30, stream=stream.cuda_stream)
+        by = 4.0 * (ic + oc) * N * H * W
+        bf = {"kernel": "pw_bf16", "us_per_launch": round(us_bf, 2), "bound": "hbm", "achieved": round(by / us_bf / 1e3, 1), "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": round(by / us_bf / 1e3 / HBM_PEAK_GBS, 4), "speedup_vs_f32": round(us / us_bf, 2),
+              "note": "opt-in reduced precision (bf16 inputs, fp32 accumulation); tolerance 2^-7 scale' sum|w x| per output"}
+    except RuntimeError:
+        pass
+    return {"bf16_opt_in": bf, "bound": "mfma", "kernel": capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc), "achieved": round(tfs, 2),
             "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tfs / FP32_MFMA_PEAK_TF, 4),
             "us_per_launch": round(us, 2), "dtype": "f32",
             "workload": "pw1x1 256->512 20x20 batch 256 fp32 (BASELINE config[2])"}

@@ -423,7 +423,7 @@ static int plan(ffgpu_exec *ex)
             d.out = tensor_ptr(ex, canon[i]);
             d.N = N; d.iw = a.w; d.ih = a.h; d.ic = a.c; d.ow = b.w; d.oh = b.h; d.oc = b.c;
             d.fs = a.fs; d.stride = a.stride; d.pad = a.pad; d.groups = a.groups; d.act = a.activation;
-            d.flags = ex->flags & FFGPU_COMPAT_V6;
+            d.flags = ex->flags & (FFGPU_COMPAT_V6 | FFGPU_BF16_PW);
             if (from_input) { d.in_cs = (long)a.w * a.h; d.in_ns = (long)a.c * a.w * a.h; }     // frame-major batch input
             else            { d.in_cs = (long)N * a.w * a.h; d.in_ns = (long)a.w * a.h; }
             d.out_cs = (long)N * b.w * b.h; d.out_ns = (long)b.w * b.h;
@@ -812,6 +812,8 @@ static ffgpu_exec *exec_create_on(ffgpu_netdev *dev, NET *net, int batch, int fl
     if (env && atoi(env)) flags |= FFGPU_COMPAT_V6;
     env = getenv("FFGPU_NO_GRAPH");
     if (env && atoi(env)) flags |= FFGPU_NO_GRAPH;
+    env = getenv("FFGPU_BF16_PW");
+    if (env && atoi(env)) flags |= FFGPU_BF16_PW;
     env = getenv("FFGPU_NO_FUSE");
     if (env && atoi(env)) flags |= FFGPU_NO_FUSE;
     const bool split = (flags & FFGPU_SPLIT2) && batch >= 2 && batch % 2 == 0 && !(flags & FFGPU_KEEP_ALL);
@@ -1306,7 +1308,7 @@ static void fill_desc(ConvDesc &d, const float *in, const float *filt, float *ou
     memset(&d, 0, sizeof d);
     d.in = in; d.filt = filt; d.out = out; d.N = batch;
     d.iw = iw; d.ih = ih; d.ic = ic; d.ow = ow; d.oh = oh; d.oc = oc;
-    d.fs = fs; d.stride = stride; d.pad = pad; d.groups = groups; d.act = act; d.flags = flags & FFGPU_COMPAT_V6;
+    d.fs = fs; d.stride = stride; d.pad = pad; d.groups = groups; d.act = act; d.flags = flags & (FFGPU_COMPAT_V6 | FFGPU_BF16_PW);
     d.in_cs = (long)batch * iw * ih; d.in_ns = (long)iw * ih;
     d.out_cs = (long)batch * ow * oh; d.out_ns = (long)ow * oh;
 }

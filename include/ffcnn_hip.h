@@ -65,6 +65,11 @@ typedef struct ffgpu_exec ffgpu_exec;     /* a planned executor: one NET x one b
                               /* are split over fewer waves (less redundant work per wave; a   */
                               /* lone chain is ~4 % slower, four in flight ~3.5 % faster)      */
 
+#define FFGPU_BF16_PW   128   /* OPT-IN reduced precision: compute-bound pointwise layers (ic, oc >= 128, >= 16 384 pixels) round  */
+                              /* inputs and weights to bf16 and accumulate in fp32 on the bf16 matrix cores (16x the fp32 rate). */
+                              /* Never the default: outputs then differ from the reference by up to 2^-7 scale' sum|w x| per   */
+                              /* value (env FFGPU_BF16_PW=1 sets it for every executor).  yolo-fastest has no such layer.      */
+
 /* ---- process / device --------------------------------------------------- */
 int         ffgpu_device_count(void);
 int         ffgpu_set_device(int ordinal);            /* hipSetDevice for this thread        */
@@ -205,7 +210,8 @@ enum {
     FFGPU_K_PW_MFMA = 4,      /* 1x1: fp32 MFMA 16x16x4, streaming (bandwidth-bound)      */
     FFGPU_K_PW_GEMM = 5,      /* 1x1: fp32 MFMA GEMM tile for compute-bound shapes (ic, oc >= 128) */
     FFGPU_K_DENSE_SMALL = 7,  /* dense 3x3/5x5 with <= 8 input channels (the first layer)   */
-    FFGPU_K_IGEMM = 8         /* dense KxK, groups == 1: implicit GEMM on fp32 MFMA (im2col gathered on the fly) */
+    FFGPU_K_IGEMM = 8,        /* dense KxK, groups == 1: implicit GEMM on fp32 MFMA (im2col gathered on the fly) */
+    FFGPU_K_PW_BF16 = 9       /* 1x1, opt-in (FFGPU_BF16_PW): bf16 inputs, fp32 accumulation, v_mfma_f32_32x32x16_bf16 */
 };
 
 /* name of the kernel `variant` resolves to for this shape (for logs/benches) */

@@ -248,6 +248,38 @@ def test_dwpw_fused_pair(env, orc, shape):
         check(got[:, n], o2, "dwpw %s frame %d vs oracle" % (shape, n))
 
 
+@pytest.mark.parametrize("shape", [(256, 512, 3, 20, 20, 2), (128, 130, 2, 10, 10, 0), (160, 255, 1, 12, 12, 1), (136, 128, 2, 20, 20, 2)])
+def test_pw_bf16(env, orc, shape):
+    """the OPT-IN bf16 pointwise variant (FFGPU_BF16_PW; never the default): inputs and weights rounded to bf16, fp32
+    accumulation.  Its own tolerance, stated here: |d| <= 2^-7 * |scale'| * sum_k |w_k x_k| + 1e-5 per output (two roundings
+    of relative size 2^-9 per product, worst case) against the fp32 oracle; and it must really differ from fp32 (i.e. run)."""
+    capi, torch = env
+    ic, oc, N, H, W, act = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f = make_filter(rng, oc, ic)
+    assert capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc, capi.FFGPU.K_PW_BF16) == "pw_bf16"
+    dx, df = torch.from_numpy(x).cuda(), torch.from_numpy(f).cuda()
+    dy = torch.full((oc * N, H, W), float("nan"), device="cuda")
+    capi.groupconv_dev(dx.data_ptr(), df.data_ptr(), dy.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act, capi.FFGPU.BF16_PW, capi.FFGPU.K_PW_BF16, None)
+    torch.cuda.synchronize()
+    got = dy.cpu().numpy().reshape(oc, N, H * W)
+    assert not np.isnan(got).any()
+    k4 = (ic + 3) & ~3
+    w, sc = f[:, :ic], np.abs(f[:, k4])
+    xf = x.reshape(ic, N, H * W)
+    worst = 0.0
+    for n in range(N):
+        ref = orc.groupconv(np.ascontiguousarray(x.reshape(ic, N, H, W)[:, n]), f, 1, 0, 1, 1, act).reshape(oc, H * W)
+        bound = 2.0 ** -7 * sc[:, None] * (np.abs(w) @ np.abs(xf[:, n])) + 1e-5
+        err = np.abs(got[:, n] - ref)
+        assert (err <= bound).all(), "pw_bf16 %s frame %d: max excess %.3g" % (shape, n, (err - bound).max())
+        worst = max(worst, float(err.max()))
+    assert worst > 1e-5, "bf16 variant returned fp32-exact results: it did not run"
+    # AUTO never picks it unless the flag is passed
+    assert capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc) in ("pw_gemm", "pw_mfma")
+
+
 def test_unsupported_variant_fails_loudly(env):
     capi, torch = env
     x = torch.zeros((4, 7, 7), device="cuda")          # W % 4 != 0: the stream kernel must refuse

@@ -17,6 +17,13 @@ filt[:, (ic + 3) & ~3] = 1.0
 s = torch.cuda.Stream()
 for rep in range(3):
     us = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2, warmup=5, iters=50, stream=s.cuda_stream)
+if os.environ.get("BF16"):
+    for rep in range(3):
+        us = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2, flags=capi.FFGPU.BF16_PW,
+                                     variant=capi.FFGPU.K_PW_BF16, warmup=5, iters=50, stream=s.cuda_stream)
+    by = 4.0 * (ic + oc) * N * H * W
+    print("pw_bf16 (opt-in, FFGPU_BF16_PW): %.1f us  %.0f GB/s algorithmic (%.2f of 8 TB/s)  %.0f TFLOP/s" % (us, by / us / 1e3, by / us / 1e3 / 8000, 2.0 * oc * ic * N * H * W / us / 1e6))
+    sys.exit(0)
 fl = 2.0 * oc * ic * N * H * W
 print("%s PX=%s old=%s: %.1f us  %.1f TFLOP/s  %.3f of 157.3" % (capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc), os.environ.get("FFGPU_PWG_PX", "2"),
       os.environ.get("FFGPU_PW_GEMM_OLD", "0"), us, fl / us / 1e6, fl / us / 1e6 / 157.3))
