@@ -206,6 +206,24 @@ def test_conv_igemm(env, orc, shape):
         check(got.reshape(oc, N, OH, OW)[:, n], o, "conv_igemm %s frame %d vs oracle" % (shape, n))
 
 
+@pytest.mark.parametrize("shape", [(32, 48, 2, 2, 11, 9, 3, 1, 1, 2), (64, 64, 4, 1, 8, 8, 3, 2, 1, 2), (48, 24, 3, 3, 7, 7, 1, 1, 0, 0), (32, 160, 2, 1, 6, 10, 5, 1, 2, 1)])
+def test_conv_igemm_grouped(env, orc, shape):
+    """grouped convolutions with >= 8 channels per group (conv-v0.c:46-51: group g uses its slice of input channels, filter
+    rows and output channels): one implicit-GEMM launch per group, against the oracle"""
+    capi, torch = env
+    ic, oc, groups, N, H, W, fs, stride, pad, act = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f = make_filter(rng, oc, fs * fs * ic // groups)
+    assert capi.kernel_name(N, W, H, ic, groups, pad, stride, fs, oc) == "conv_igemm"
+    got = run_dev(capi, torch, x, f, N, W, H, ic, groups, pad, stride, fs, oc, act, capi.FFGPU.K_AUTO)
+    OH, OW = (H + 2 * pad - fs) // stride + 1, (W + 2 * pad - fs) // stride + 1
+    xf = x.reshape(ic, N, H, W)
+    for n in range(N):
+        o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, groups, pad, stride, fs, act)
+        check(got.reshape(oc, N, OH, OW)[:, n], o, "grouped igemm %s frame %d vs oracle" % (shape, n))
+
+
 def test_conv_igemm_frame_major_input_and_residual(env, orc):
     """the strides the executor hands over for a first layer (frame-major batch input) and a fused shortcut"""
     capi, torch = env
