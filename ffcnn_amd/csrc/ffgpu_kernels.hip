@@ -233,6 +233,51 @@ __global__ void k_input_bgr(const unsigned char *bgr, float *out, int N, int w, 
     }
 }
 
+// the same for W % 4 == 0: a thread owns 4 consecutive output pixels of one row (one 32-bit division per thread, blockIdx.y =
+// frame), reads their source bytes -- 12 contiguous bytes as three dwords when the image is not resized -- and writes
+// one 16-byte store per colour plane.  Same arithmetic per pixel as above ((byte - mean) * norm, two roundings).
+__global__ void __launch_bounds__(256) k_input_bgr4(const unsigned char *bgr, float *out, int w, int h, int W, int H,
+                                                    int sw, int sh, int s1, int s2, InputP p)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const unsigned wq = (unsigned)W >> 2, t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= wq * (unsigned)H) return;
+    const int y = (int)(t / wq), x0 = (int)(t - (unsigned)y * wq) * 4, n = blockIdx.y;
+    const long pitch = (long)((w * 3 + 3) & ~3);
+    f4 r = { 0.f, 0.f, 0.f, 0.f }, g = r, b = r;
+    if (y < sh && x0 < sw) {
+        const unsigned char *row = bgr + (long)n * pitch * h + (long)((long)y * s1 / s2) * pitch;
+        unsigned char px[4][3];
+        if (s1 == s2 && x0 + 3 < sw) {                              // not resized: 12 contiguous bytes, dword aligned (pitch % 4 == 0, 3 x0 % 4 == 0)
+            const unsigned *q = reinterpret_cast<const unsigned *>(row + 3 * x0);
+            const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
+            const unsigned char by[12] = { (unsigned char)d0, (unsigned char)(d0 >> 8), (unsigned char)(d0 >> 16), (unsigned char)(d0 >> 24),
+                                           (unsigned char)d1, (unsigned char)(d1 >> 8), (unsigned char)(d1 >> 16), (unsigned char)(d1 >> 24),
+                                           (unsigned char)d2, (unsigned char)(d2 >> 8), (unsigned char)(d2 >> 16), (unsigned char)(d2 >> 24) };
+#pragma unroll
+            for (int i = 0; i < 4; i++) { px[i][0] = by[3 * i]; px[i][1] = by[3 * i + 1]; px[i][2] = by[3 * i + 2]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int x = min(x0 + i, sw - 1);
+                const unsigned char *s = row + (long)((long)x * s1 / s2) * 3;
+                px[i][0] = s[0]; px[i][1] = s[1]; px[i][2] = s[2];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool in = x0 + i < sw;
+            r[i] = in ? ((float)px[i][2] - p.mean[0]) * p.norm[0] : 0.f;
+            g[i] = in ? ((float)px[i][1] - p.mean[1]) * p.norm[1] : 0.f;
+            b[i] = in ? ((float)px[i][0] - p.mean[2]) * p.norm[2] : 0.f;
+        }
+    }
+    float *o = out + (long)n * 3 * H * W + (long)y * W + x0;
+    *reinterpret_cast<f4 *>(o) = r;
+    *reinterpret_cast<f4 *>(o + (long)H * W) = g;
+    *reinterpret_cast<f4 *>(o + 2L * H * W) = b;
+}
+
 // ---------------------------------------------------------------------------
 // YOLO head decode (ffcnn.c:438-474).  One thread per (frame, cell, anchor);
 // lanes run along x so the 85 strided channel reads are coalesced.  exp() is
@@ -521,6 +566,11 @@ int ffgpu_launch_input_bgr(const unsigned char *bgr, float *out, int N, int w, i
 {
     InputP p;
     for (int i = 0; i < 3; i++) { p.mean[i] = mean[i]; p.norm[i] = norm[i]; }
+    if (W % 4 == 0 && N <= 65535 && (long)W * H < (1L << 31)) {
+        hipLaunchKernelGGL(k_input_bgr4, dim3((unsigned)(((long)(W / 4) * H + 255) / 256), (unsigned)N), dim3(256), 0, s, bgr, out, w, h, W, H, sw, sh, s1, s2, p);
+        LAUNCH_OK("input_bgr4");
+        return 0;
+    }
     hipLaunchKernelGGL(k_input_bgr, dim3(grid_for((long)N * H * W, 256)), dim3(256), 0, s, bgr, out, N, w, h, W, H, sw, sh, s1, s2, p);
     LAUNCH_OK("input_bgr");
     return 0;
