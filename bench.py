@@ -213,7 +213,7 @@ def pw_roofline(torch, capi, stream):
     bf = None
     try:
         us_bf = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2, flags=capi.FFGPU.BF16_PW,
-                                        variant=capi.FFGPU.K_PW_BF16, warmup=4, iters=30, stream=stream.cuda_stream)
+                                        variant=capi.FFGPU.K_AUTO, warmup=4, iters=30, stream=stream.cuda_stream)
         by = 4.0 * (ic + oc) * N * H * W
         bf = {"kernel": "pw_bf16", "us_per_launch": round(us_bf, 2), "bound": "hbm", "achieved": round(by / us_bf / 1e3, 1), "peak": HBM_PEAK_GBS,
               "unit": "GB/s", "frac": round(by / us_bf / 1e3 / HBM_PEAK_GBS, 4), "speedup_vs_f32": round(us / us_bf, 2),

@@ -20,7 +20,7 @@ for rep in range(3):
 if os.environ.get("BF16"):
     for rep in range(3):
         us = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2, flags=capi.FFGPU.BF16_PW,
-                                     variant=capi.FFGPU.K_PW_BF16, warmup=5, iters=50, stream=s.cuda_stream)
+                                     variant=capi.FFGPU.K_AUTO, warmup=5, iters=50, stream=s.cuda_stream)
     by = 4.0 * (ic + oc) * N * H * W
     print("pw_bf16 (opt-in, FFGPU_BF16_PW): %.1f us  %.0f GB/s algorithmic (%.2f of 8 TB/s)  %.0f TFLOP/s" % (us, by / us / 1e3, by / us / 1e3 / 8000, 2.0 * oc * ic * N * H * W / us / 1e6))
     sys.exit(0)
