@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config[2] (1x1, 256 -> 512, 20x20, batch 256) on the pointwise GEMM kernels: microseconds, TFLOP/s, fraction of
-the fp32 matrix peak; FFGPU_PWG_PX / FFGPU_PW_GEMM_OLD choose the variant."""
+the fp32 matrix peak; FFGPU_PWG_PX / FFGPU_PWG_GLDS / FFGPU_PWG_DBG choose variants and ablations; BF16=1 times the opt-in bf16 kernel."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,5 +25,5 @@ if os.environ.get("BF16"):
     print("pw_bf16 (opt-in, FFGPU_BF16_PW): %.1f us  %.0f GB/s algorithmic (%.2f of 8 TB/s)  %.0f TFLOP/s" % (us, by / us / 1e3, by / us / 1e3 / 8000, 2.0 * oc * ic * N * H * W / us / 1e6))
     sys.exit(0)
 fl = 2.0 * oc * ic * N * H * W
-print("%s PX=%s old=%s: %.1f us  %.1f TFLOP/s  %.3f of 157.3" % (capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc), os.environ.get("FFGPU_PWG_PX", "2"),
-      os.environ.get("FFGPU_PW_GEMM_OLD", "0"), us, fl / us / 1e6, fl / us / 1e6 / 157.3))
+print("%s PX=%s: %.1f us  %.1f TFLOP/s  %.3f of 157.3" % (capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc), os.environ.get("FFGPU_PWG_PX", "2"),
+      us, fl / us / 1e6, fl / us / 1e6 / 157.3))
