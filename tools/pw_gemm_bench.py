@@ -25,5 +25,5 @@ if os.environ.get("BF16"):
     print("pw_bf16 (opt-in, FFGPU_BF16_PW): %.1f us  %.0f GB/s algorithmic (%.2f of 8 TB/s)  %.0f TFLOP/s" % (us, by / us / 1e3, by / us / 1e3 / 8000, 2.0 * oc * ic * N * H * W / us / 1e6))
     sys.exit(0)
 fl = 2.0 * oc * ic * N * H * W
-print("%s PX=%s: %.1f us  %.1f TFLOP/s  %.3f of 157.3" % (capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc), os.environ.get("FFGPU_PWG_PX", "2"),
+print("%s narrow=%s: %.1f us  %.1f TFLOP/s  %.3f of 157.3" % (capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc), os.environ.get("FFGPU_PWG_NARROW", "1"),
       us, fl / us / 1e6, fl / us / 1e6 / 157.3))
