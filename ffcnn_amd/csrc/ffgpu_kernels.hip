@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <type_traits>
 #include <vector>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include "ffgpu_dev.hpp"
@@ -510,6 +511,28 @@ static inline int grid_for(long total, int block, int cap = 256 * 16)
         if (e_ != hipSuccess) { ffgpu_set_error("%s launch failed: %s", what, hipGetErrorString(e_)); return -1; } \
     } while (0)
 
+// Dynamic LDS above 64 KB has to be allowed per kernel AND per device: a node (ffgpu_node.inc) plans the same kernels on every
+// GPU of the box from one process, so "raised once per process" is not enough.
+static int lds_allow(const void *fn, size_t lds, const char *what)
+{
+    if (lds <= 64 * 1024) return 0;
+    struct Seen { const void *fn; int dev; size_t lds; };
+    static std::mutex mu;
+    static std::vector<Seen> seen;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    Seen *e = nullptr;
+    for (auto &k : seen) if (k.fn == fn && k.dev == dev) e = &k;
+    if (e && e->lds >= lds) return 0;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        ffgpu_set_error("%s: cannot raise dynamic LDS to %zu bytes", what, lds);
+        return -1;
+    }
+    if (e) e->lds = lds; else seen.push_back({ fn, dev, lds });
+    return 0;
+}
+
 #include "ffgpu_conv_kernels.inc"
 
 int ffgpu_launch_pool(const float *in, float *out, int N, int c, int w, int h, int fs, int stride, int is_max, hipStream_t s)
@@ -596,12 +619,7 @@ int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap,
                            dets, dets_host, ring_ctr, thresh, use_min, prm);
     } else {
         const size_t lds = (size_t)13 * p2;
-        static bool raised = false;                                // > 64 KB of dynamic LDS needs the attribute (once per process)
-        if (lds > 64 * 1024 && !raised) {
-            if (hipFuncSetAttribute((const void *)k_nms<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 13 * FFGPU_NMS_LDS_CAP) != hipSuccess) {
-                ffgpu_set_error("nms: cannot raise the dynamic LDS limit"); return -1; }
-            raised = true;
-        }
+        if (lds_allow((const void *)k_nms<false>, lds > 64 * 1024 ? (size_t)13 * FFGPU_NMS_LDS_CAP : lds, "nms")) return -1;
         hipLaunchKernelGGL(k_nms<false>, dim3(N), dim3(256), lds, s, cand, cand_key, ncand, cap, p2, bbox_max, full, nullptr,
                            dets, dets_host, ring_ctr, thresh, use_min, prm);
     }

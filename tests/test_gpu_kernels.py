@@ -161,7 +161,10 @@ def test_dw5_channel_pairs(env, orc, shape, pair, monkeypatch):
     test_dw_lds(env, orc, shape)
 
 
-@pytest.mark.parametrize("shape", [(256, 512, 2, 20, 20, 2), (128, 255, 1, 20, 20, 0), (64, 130, 3, 10, 10, 2), (100, 200, 1, 12, 12, 1)])
+# the last three fill the chip more than once (main tiles + narrow tiles behind them): ragged K (72 = 4.5 chunks), ragged channel
+# tiles (300, 255), sigmoid
+@pytest.mark.parametrize("shape", [(256, 512, 2, 20, 20, 2), (128, 255, 1, 20, 20, 0), (64, 130, 3, 10, 10, 2), (100, 200, 1, 12, 12, 1),
+                                   (72, 300, 83, 20, 20, 2), (64, 256, 164, 20, 20, 0), (80, 255, 170, 20, 20, 3)])
 def test_pw_gemm(env, orc, shape):
     capi, torch = env
     ic, oc, N, H, W, act = shape
