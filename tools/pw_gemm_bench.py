@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config[2] (1x1, 256 -> 512, 20x20, batch 256) on the pointwise GEMM kernels: microseconds, TFLOP/s, fraction of
-the fp32 matrix peak; FFGPU_PWG_PX / FFGPU_PWG_GLDS / FFGPU_PWG_DBG choose variants and ablations; BF16=1 times the opt-in bf16 kernel."""
+the fp32 matrix peak; FFGPU_PWG_DBG (1 no loads in the loop, 8 no epilogue: wrong results) and FFGPU_PWG_NARROW=0 are the ablations; BF16=1 times the
+opt-in bf16 kernel."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
