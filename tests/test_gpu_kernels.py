@@ -123,6 +123,7 @@ DWL_SHAPES = [  # (C, N, H, W, fs, stride, act, compat)
     (24, 2, 160, 160, 3, 2, 2, 0), (32, 1, 80, 80, 3, 2, 2, 0), (136, 2, 20, 20, 3, 1, 2, 0), (224, 3, 10, 10, 3, 1, 2, 0),
     (96, 2, 10, 10, 5, 1, 2, 0), (96, 2, 10, 10, 5, 1, 2, 1), (120, 1, 20, 20, 5, 1, 2, 0), (120, 2, 20, 20, 5, 1, 2, 1),
     (5, 3, 7, 9, 3, 1, 0, 0), (4, 1, 7, 7, 3, 2, 1, 0), (3, 2, 6, 8, 5, 1, 2, 0), (2, 1, 33, 45, 5, 2, 2, 0), (3, 1, 1, 1, 3, 1, 2, 0),
+    (136, 3, 45, 68, 3, 1, 3, 0), (40, 5, 37, 50, 5, 1, 2, 0),   # several planes per workgroup AND a partial last band (found by tests/test_gpu_fuzz.py)
 ]
 
 
