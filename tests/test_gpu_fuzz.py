@@ -3,6 +3,8 @@ against the CPU oracle, frame by frame: pointwise / depthwise / dense / grouped,
 channel counts around every tile size (4, 16, 32, 64, 128, 256), odd widths and heights, batches 1-5, all four activations
 (conv.h:4-7 semantics, conv-v0.c:7-31 is what the oracle restates).  The point is the seams BETWEEN the specialised kernels:
 a shape that just misses one kernel's predicate must land on another that computes the same thing."""
+import os
+
 import numpy as np
 import pytest
 
@@ -46,7 +48,7 @@ def draw(rng):
     return kind, ic, oc, groups, fs, stride, pad, N, H, W, act
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FFCNN_FUZZ_SEED0", "0")), int(os.environ.get("FFCNN_FUZZ_SEED0", "0")) + int(os.environ.get("FFCNN_FUZZ_SHAPES", "8"))))
 def test_random_geometries_vs_oracle(orc, seed):
     import torch
     from ffcnn_amd import capi

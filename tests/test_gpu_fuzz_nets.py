@@ -1,0 +1,147 @@
+"""Seeded random darknet cfgs in yolo-fastest's grammar (stem 3x3 s2, inverted-residual blocks = 1x1 expand / depthwise 3x3 s1|s2
+/ 1x1 linear project [+ dropout + shortcut], one or two 1x1 + yolo heads) through the PLANNER and the fused kernels, against the
+oracle (which restates ffcnn.c:476-520 layer by layer): every tensor the fused executor still materialises, for every frame,
+at plane sizes and channel counts the shipped model never has (k_front / k_irb_thin / k_irbw / k_irbw2 / k_irb tile logic,
+group splits, stride-2 halos, ragged last tiles, 8..200 expanded channels), default and FFGPU_CONCURRENT plans, batches 1-6."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import _write_random_weights, boxes_match, close
+
+pytestmark = pytest.mark.gpu
+
+
+def conv(filters, size, stride, act, groups=1, bn=1):
+    s = "[convolutional]\n"
+    if groups > 1:
+        s += "groups=%d\n" % groups
+    return s + "filters=%d\nsize=%d\nstride=%d\npad=%d\n%sactivation=%s\n\n" % (filters, size, stride, 1 if size > 1 else 0, "batch_normalize=1\n" if bn else "", act)
+
+
+def random_cfg(rng):
+    """-> (cfg text, (H, W)).  Layers are counted while the text grows so that routes can name absolute indices."""
+    big = rng.random() < 0.3                                    # inputs large enough for the big-plane plans (k_front, k_irb_thin)
+    W = int(rng.choice([256, 320]) if big else rng.choice([64, 96, 128, 160, 224]))
+    H = int(rng.choice([192, 320]) if big else rng.choice([64, 96, 128, 160]))
+    classes = int(rng.choice([1, 2, 5]))
+    L = {"n": 0, "txt": "[net]\nwidth=%d\nheight=%d\nchannels=3\n\n" % (W, H)}
+
+    def add(t, k=1):
+        L["txt"] += t
+        L["n"] += k
+        return L["n"] - 1                                       # index of the last layer added
+
+    c = 8 if big else int(rng.choice([4, 8, 8, 12, 16]))
+    add(conv(c, 3, 2, "leaky"))
+    w, h = W // 2, H // 2
+    if big or rng.random() < 0.5:                               # yolo-fastest's opening: pointwise, depthwise, linear projection
+        c2 = 4 if big else int(rng.choice([4, 8]))
+        add(conv(c, 1, 1, "leaky") + conv(c, 3, 1, "leaky", groups=c) + conv(c2, 1, 1, "linear"), 3)
+        c = c2
+    taps = []                                                   # (layer index, channels, w, h) of block outputs, for the second head
+    nblocks = int(rng.integers(3, 9))
+    for b in range(nblocks):
+        stride = 2 if (rng.random() < 0.35 and min(w, h) >= 8) else 1
+        ec = int(rng.choice([8, 16, 24, 32, 40, 48, 72, 96, 136, 200]))
+        oc = c if (stride == 1 and rng.random() < 0.6) else int(rng.choice([4, 8, 16, 24, 48]))
+        last = add(conv(ec, 1, 1, "leaky") + conv(ec, 3, stride, "leaky", groups=ec) + conv(oc, 1, 1, "linear"), 3)
+        if stride == 1 and oc == c:
+            last = add("[dropout]\nprobability=.15\n\n[shortcut]\nfrom=-5\nactivation=linear\n\n", 2)
+        c = oc
+        w, h = (w + stride - 1) // stride, (h + stride - 1) // stride
+        taps.append((last, c, w, h))
+    if rng.random() < 0.4:                                      # SPP: three max pools of the same tensor + the tensor (ffcnn.c:381-394)
+        base = L["n"] - 1
+        add("[maxpool]\nsize=3\nstride=1\n\n[route]\nlayers = %d\n\n[maxpool]\nsize=5\nstride=1\n\n[route]\nlayers = %d\n\n[maxpool]\nsize=9\nstride=1\n\n"
+            "[route]\nlayers = -1,-3,-5,%d\n\n" % (base, base, base), 6)
+        c *= 4
+        add(conv(int(rng.choice([16, 24, 48])), 1, 1, "leaky"))
+        c = None
+
+    def head(mask, dw5):
+        if dw5:                                                 # the heads' 5x5 depthwise + pointwise pairs (layers 116-119 / 125-128)
+            hc = int(rng.choice([16, 24, 40, 96]))
+            add(conv(hc, 1, 1, "leaky") + "[convolutional]\ngroups=%d\nfilters=%d\nsize=5\nstride=1\npad=1\nbatch_normalize=1\nactivation=leaky\n\n" % (hc, hc) + conv(hc, 1, 1, "linear"), 3)
+        add(conv(3 * (5 + classes), 1, 1, "linear", bn=0))
+        add("[yolo]\nmask = %s\nanchors = 6,8, 10,14, 20,18, 30,40, 50,44, 70,80\nclasses=%d\nignore_thresh = .55\nscale_x_y = 1.05\n\n" % (mask, classes))
+
+    feat = L["n"] - 1                                           # what the first head reads
+    head("3,4,5", rng.random() < 0.5)
+    r = rng.random()
+    if r < 0.35:                                                # a second head on the same tensor through a route
+        add("[route]\nlayers = %d\n\n" % feat)
+        add(conv(int(rng.choice([16, 32])), 1, 1, "leaky"))
+        head("0,1,2", rng.random() < 0.5)
+    elif r < 0.7:                                               # ... or on the upsampled tensor joined with an earlier block output of twice the size
+        wf, hf = w, h
+        cand = [t for t in taps if t[2] == 2 * wf and t[3] == 2 * hf]
+        if cand:
+            t = cand[int(rng.integers(0, len(cand)))]
+            add("[route]\nlayers = %d\n\n" % feat)
+            add("[upsample]\nstride=2\n\n")
+            add("[route]\nlayers = -1,%d\n\n" % t[0])
+            head("0,1,2", rng.random() < 0.5)
+    return L["txt"], (H, W)
+
+
+SEEDS = range(int(os.environ.get("FFCNN_FUZZ_SEED0", "0")), int(os.environ.get("FFCNN_FUZZ_SEED0", "0")) + int(os.environ.get("FFCNN_FUZZ_NETS", "12")))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_nets_fused_vs_oracle(orc, tmp_path, seed):
+    from ffcnn_amd import capi as F
+    F.lib()
+    rng = np.random.default_rng(9100 + seed)
+    txt, (H, W) = random_cfg(rng)
+    cfg = str(tmp_path / "rnd.cfg")
+    open(cfg, "w").write(txt)
+    o = orc.Oracle(cfg=cfg, weights=None)
+    wpath = str(tmp_path / "rnd.weights")
+    _write_random_weights(wpath, o, 100 + seed)
+    o.close()
+    o = orc.Oracle(cfg=cfg, weights=wpath)
+    B = int(rng.integers(1, 7))
+    frames = rng.uniform(0, 1, (B, 3, H, W)).astype(np.float32)
+    acts, cands, boxes = [], [], []
+    for f in range(B):
+        o.input[...] = frames[f]
+        o.n.s1, o.n.s2 = 1, 1
+        o.forward(0)
+        acts.append({i: o.layer_out(i).copy() for i in range(o.nlayers) if o.layer_out(i) is not None})
+        cands.append(o.candidates)
+        boxes.append(o.boxes)
+    # a candidate whose confidence sits within 2e-3 of the threshold may legitimately flip under the 1e-3 activation tolerance
+    edge = any(abs(float(c["score"]) - 0.55) < 2e-3 for cs in cands for c in cs)
+    with F.Net(cfg, wpath) as n:
+        assert n.layer_num == o.nlayers and np.array_equal(n.weights_host(), o.weights())
+        for flags in (F.FFGPU.KEEP_ALL, F.FFGPU.KEEP_ALL | F.FFGPU.CONCURRENT, 0):
+            with n.executor(B, flags) as ex:
+                ex.set_scale(1, 1)
+                ex.forward_host(frames)
+                dets = ex.read_dets()
+                nconv = sum(1 for i in range(o.nlayers) if o.layer(i).kind == 0)
+                assert ex.kernel_count < nconv + 4, "no fusion happened: %d launches for %d conv layers" % (ex.kernel_count, nconv)
+                seen = 0
+                if flags & F.FFGPU.KEEP_ALL:
+                    for i in sorted(acts[0]):
+                        if n.layer(i).type == 4:
+                            continue
+                        try:
+                            ex.read_layer(i, 0)
+                        except RuntimeError as e:
+                            assert "not materialised" in str(e)
+                            continue
+                        seen += 1
+                        for f in range(B):
+                            close(ex.read_layer(i, f), acts[f][i], "seed %d flags %d frame %d layer %d (%s)\n%s" % (seed, flags, f, i, ex.plan_text() if hasattr(ex, "plan_text") else "", ""))
+                    assert seen >= 3
+                if not edge:
+                    for f in range(B):
+                        assert dets[f]["ncand"] == len(cands[f]), "seed %d flags %d frame %d" % (seed, flags, f)
+                        # random weights can drive exp(tw) to 1e10 pixels: boxes are compared where the 0.05-pixel tolerance
+                        # means something (every candidate within +-2000 pixels); the full list, not the 128 of the record
+                        if all(abs(float(c[k])) < 2000 for c in cands[f] for k in ("x1", "y1", "x2", "y2")):
+                            boxes_match(ex.read_boxes(f), boxes[f], "seed %d flags %d frame %d boxes" % (seed, flags, f))
+    o.close()
