@@ -43,6 +43,10 @@ def random_cfg(rng):
     taps = []                                                   # (layer index, channels, w, h) of block outputs, for the second head
     nblocks = int(rng.integers(3, 9))
     for b in range(nblocks):
+        if rng.random() < 0.15:                                 # not an inverted-residual block: dense 3x3 + 1x1 with the shortcut in the epilogue
+            last = add(conv(c, 3, 1, "leaky") + conv(c, 1, 1, "linear") + "[shortcut]\nfrom=-3\nactivation=%s\n\n" % rng.choice(["linear", "leaky", "relu"]), 3)
+            taps.append((last, c, w, h))
+            continue
         stride = 2 if (rng.random() < 0.35 and min(w, h) >= 8) else 1
         ec = int(rng.choice([8, 16, 24, 32, 40, 48, 72, 96, 136, 200]))
         oc = c if (stride == 1 and rng.random() < 0.6) else int(rng.choice([4, 8, 16, 24, 48]))
@@ -139,6 +143,8 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed):
                     assert seen >= 3
                 if not edge:
                     for f in range(B):
+                        if len(cands[f]) >= 8192:                   # the oracle's own candidate buffer is full (not the reference's limit)
+                            continue
                         assert dets[f]["ncand"] == len(cands[f]), "seed %d flags %d frame %d" % (seed, flags, f)
                         # random weights can drive exp(tw) to 1e10 pixels: boxes are compared where the 0.05-pixel tolerance
                         # means something (every candidate within +-2000 pixels); the full list, not the 128 of the record
