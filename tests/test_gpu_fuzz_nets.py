@@ -143,9 +143,12 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed):
                     assert seen >= 3
                 if not edge:
                     for f in range(B):
-                        if len(cands[f]) >= 8192:                   # the oracle's own candidate buffer is full (not the reference's limit)
-                            continue
-                        assert dets[f]["ncand"] == len(cands[f]), "seed %d flags %d frame %d" % (seed, flags, f)
+                        # more candidates than bbox_max (ffcnn.c:243,463: input bytes / 24): the reference keeps the first bbox_max in
+                        # emission order, and so must the boxes here; the record's ncand is the untruncated count
+                        if len(cands[f]) < o.n.cap:
+                            assert dets[f]["ncand"] == len(cands[f]), "seed %d flags %d frame %d" % (seed, flags, f)
+                        else:
+                            assert dets[f]["ncand"] >= len(cands[f])
                         # random weights can drive exp(tw) to 1e10 pixels: boxes are compared where the 0.05-pixel tolerance
                         # means something (every candidate within +-2000 pixels); the full list, not the 128 of the record
                         if all(abs(float(c[k])) < 2000 for c in cands[f] for k in ("x1", "y1", "x2", "y2")):
