@@ -149,7 +149,9 @@ def eight(orc, test_image):
     return fr, runs
 
 
-@pytest.mark.parametrize("batch,flags", [(32, 0), (32, 64), (64, 0), (64, 64)])
+# (the odd sizes: plans are functions of the batch -- tile splits, waves per tile, frames per workgroup -- and a batch that is not a
+#  multiple of anything exercises their ragged ends)
+@pytest.mark.parametrize("batch,flags", [(32, 0), (32, 64), (64, 0), (64, 64), (5, 64), (7, 0), (13, 64), (24, 0), (48, 64), (100, 64), (129, 0)])
 def test_big_batch_plans_activations(F, net, eight, batch, flags):
     """the plans big batches take (k_front, tile splits, band lengths; FFGPU_CONCURRENT = what bench.py runs): ten
     materialised tensors of EVERY frame against the oracle, frames in a scrambled order so that neighbouring planes of a
