@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def draw(rng):
-    kind = rng.choice(["pw", "dw", "dense", "grouped"], p=[0.35, 0.25, 0.25, 0.15])
+    kind = rng.choice(["pw", "dw", "dense", "grouped", "dwbig", "first"], p=[0.3, 0.2, 0.2, 0.12, 0.1, 0.08])
     N = int(rng.integers(1, 6))
     act = int(rng.integers(0, 4))
     edge = [1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 96, 120, 127, 128, 129, 136, 200, 255, 256, 260]
@@ -30,6 +30,22 @@ def draw(rng):
         stride = int(rng.choice([1, 1, 2, 3]))
         pad = int(rng.choice([fs // 2, fs // 2, 0, 1]))
         H, W = int(rng.integers(fs, 70)), int(rng.integers(fs, 90))
+    elif kind == "dwbig":                                        # the streaming depthwise kernel's domain (W % 4 == 0, 40..512) and just outside it
+        ic = oc = groups = int(rng.integers(1, 17))
+        fs, stride, pad = 3, 1, 1
+        W = int(rng.choice([40, 44, 64, 100, 128, 160, 252, 256, 260, 320, 512, 516, int(rng.integers(36, 530))]))
+        H = int(rng.integers(2, 140))
+        N = int(rng.integers(1, 4))
+        if act == 3 and rng.random() < 0.7:
+            act = 2
+    elif kind == "first":                                        # a darknet first layer: 3 channels, 3x3 stride 2, up to the four-pixel kernel's batch sizes
+        ic, groups = 3, 1
+        oc = int(rng.choice([8, 8, 16, 5]))
+        fs, stride, pad = 3, 2, 1
+        W, H = int(rng.choice([64, 96, 160, 224, 320, 322])), int(rng.choice([64, 128, 192, 320, 318]))
+        N = int(rng.choice([1, 2, 5, 11])) if W * H < 320 * 320 else int(rng.choice([1, 3, 11]))
+        if act == 3:
+            act = 2
     elif kind == "dense":
         ic, oc, groups = int(rng.choice([1, 3, 4, 7, 8, 9, 16, 33, 64])), int(rng.choice([1, 5, 8, 16, 21, 64, 70, 130])), 1
         fs = int(rng.choice([1, 2, 3, 3, 5]))
