@@ -86,4 +86,6 @@ def test_random_geometries_vs_oracle(orc, seed):
         for n in range(N):
             ref = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, groups, pad, stride, fs, act)
             check(got.reshape(oc, N, oh, ow)[:, n], ref.reshape(oc, oh, ow), what + " frame %d" % n)
+            if n == 0 and case % 3 == 0:                        # the conv.h drop-in itself (host pointers, one frame: conv.h:4-7)
+                check(capi.groupconv(np.ascontiguousarray(xf[:, 0]), f, groups, pad, stride, fs, act), ref.reshape(oc, oh, ow), what + " (conv.h drop-in)")
     assert len(picked) >= 3, picked                              # the draw reaches several kernels per seed
