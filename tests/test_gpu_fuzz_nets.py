@@ -47,6 +47,11 @@ def random_cfg(rng):
             last = add(conv(c, 3, 1, "leaky") + conv(c, 1, 1, "linear") + "[shortcut]\nfrom=-3\nactivation=%s\n\n" % rng.choice(["linear", "leaky", "relu"]), 3)
             taps.append((last, c, w, h))
             continue
+        if rng.random() < 0.1:                                  # ... or the shortcut straight behind a dense / grouped 3x3 (the implicit-GEMM epilogue)
+            g = 2 if (c % 2 == 0 and rng.random() < 0.4) else 1
+            last = add(conv(c, 3, 1, str(rng.choice(["linear", "leaky"])), groups=g) + "[shortcut]\nfrom=-2\nactivation=%s\n\n" % rng.choice(["linear", "leaky"]), 2)
+            taps.append((last, c, w, h))
+            continue
         stride = 2 if (rng.random() < 0.35 and min(w, h) >= 8) else 1
         ec = int(rng.choice([8, 16, 24, 32, 40, 48, 72, 96, 136, 200]))
         oc = c if (stride == 1 and rng.random() < 0.6) else int(rng.choice([4, 8, 16, 24, 48]))
@@ -153,4 +158,47 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed):
                         # means something (every candidate within +-2000 pixels); the full list, not the 128 of the record
                         if all(abs(float(c[k])) < 2000 for c in cands[f] for k in ("x1", "y1", "x2", "y2")):
                             boxes_match(ex.read_boxes(f), boxes[f], "seed %d flags %d frame %d boxes" % (seed, flags, f))
+    o.close()
+
+
+GROUPED_CFG = "[net]\nwidth=64\nheight=64\nchannels=3\n\n" + conv(16, 3, 2, "leaky") + conv(48, 1, 1, "leaky") + \
+    conv(48, 3, 1, "linear", groups=2) + "[shortcut]\nfrom=-2\nactivation=leaky\n\n" + conv(64, 3, 2, "leaky", groups=4) + \
+    conv(32, 3, 1, "leaky", groups=2) + conv(21, 1, 1, "linear", bn=0) + \
+    "[yolo]\nmask = 0,1,2\nanchors = 6,8, 10,14, 20,18, 30,40, 50,44, 70,80\nclasses=2\nignore_thresh = .55\nscale_x_y = 1.05\n\n"
+
+
+def test_grouped_dense_layers_in_an_executor(orc, tmp_path):
+    """grouped 3x3 convolutions with 8+ channels per group inside a PLANNED net (the implicit-GEMM kernel with one plan-time
+    weight image per group): found by the random nets -- the image buffer was sized for one group and the second group's
+    image overwrote the next layer's.  Every layer, fused and unfused, three frames."""
+    from ffcnn_amd import capi as F
+    F.lib()
+    cfg = str(tmp_path / "grouped.cfg")
+    open(cfg, "w").write(GROUPED_CFG)
+    o = orc.Oracle(cfg=cfg, weights=None)
+    wpath = str(tmp_path / "grouped.weights")
+    _write_random_weights(wpath, o, 11)
+    o.close()
+    o = orc.Oracle(cfg=cfg, weights=wpath)
+    rng = np.random.default_rng(12)
+    frames = rng.uniform(0, 1, (3, 3, 64, 64)).astype(np.float32)
+    with F.Net(cfg, wpath) as n:
+        for flags in (F.FFGPU.KEEP_ALL | F.FFGPU.NO_FUSE, F.FFGPU.KEEP_ALL):
+            with n.executor(3, flags) as ex:
+                ex.set_scale(1, 1)
+                ex.forward_host(frames)
+                for f in range(3):
+                    o.input[...] = frames[f]
+                    o.n.s1, o.n.s2 = 1, 1
+                    o.forward(0)
+                    for i in range(o.nlayers):
+                        ref = o.layer_out(i)
+                        if ref is None:
+                            continue
+                        try:
+                            a = ex.read_layer(i, f)
+                        except RuntimeError as e:
+                            assert "not materialised" in str(e)
+                            continue
+                        close(a, ref, "grouped cfg flags %d frame %d layer %d" % (flags, f, i))
     o.close()
