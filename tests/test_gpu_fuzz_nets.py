@@ -95,15 +95,107 @@ def random_cfg(rng):
     return L["txt"], (H, W)
 
 
+def random_generic_cfg(rng):
+    """A random layer GRAPH over everything the ffcnn grammar has (ffcnn.c:127-240): convolutions of any size / stride /
+    padding / grouping / activation, max and average pools (size 2..5, stride 1..3), upsample, dropout, shortcuts that reach
+    back over several layers, routes joining one to three earlier tensors, one to three yolo heads.  Shapes are tracked so that
+    every join is legal; -> (text, (H, W))."""
+    W, H = int(rng.choice([32, 64, 96, 128])), int(rng.choice([32, 64, 96]))
+    classes = int(rng.choice([1, 3]))
+    txt = "[net]\nwidth=%d\nheight=%d\nchannels=3\n\n" % (W, H)
+    shapes = []                                                 # per layer: (c, w, h)
+    cur = (3, W, H)
+
+    def emit(t, shape):
+        nonlocal txt, cur
+        txt += t
+        shapes.append(shape)
+        cur = shape
+
+    def conv_any():
+        c, w, h = cur
+        fs = int(rng.choice([1, 1, 3, 3, 3, 5, 2]))
+        stride = int(rng.choice([1, 1, 1, 2])) if min(w, h) >= 8 else 1
+        pad = int(rng.choice([1, 1, 0])) if fs > 1 else 0      # darknet: pad=1 -> size / 2
+        padpx = fs // 2 if pad else 0
+        ow, oh = (w + 2 * padpx - fs) // stride + 1, (h + 2 * padpx - fs) // stride + 1
+        if ow < 1 or oh < 1:
+            return False
+        oc = int(rng.choice([4, 6, 8, 12, 16, 24, 32, 40, 64]))
+        groups = 1
+        r = rng.random()
+        if r < 0.2 and fs > 1:
+            oc, groups = c, c                                   # depthwise
+        elif r < 0.35:
+            for g in (2, 3, 4, 8):
+                if c % g == 0 and rng.random() < 0.5:
+                    groups = g
+                    oc = g * int(rng.choice([2, 4, 8, 12]))
+                    break
+        act = str(rng.choice(["leaky", "leaky", "relu", "linear"]))
+        bn = int(rng.random() < 0.8)
+        t = "[convolutional]\n" + ("groups=%d\n" % groups if groups > 1 else "") + "filters=%d\nsize=%d\nstride=%d\npad=%d\n%sactivation=%s\n\n" % (
+            oc, fs, stride, pad, "batch_normalize=1\n" if bn else "", act)
+        emit(t, (oc, ow, oh))
+        return True
+
+    emit("[convolutional]\nfilters=%d\nsize=3\nstride=%d\npad=1\nbatch_normalize=1\nactivation=leaky\n\n" % (int(rng.choice([4, 8, 16])), int(rng.choice([1, 2]))),
+         None)
+    shapes[-1] = cur = (int(txt.split("filters=")[1].split("\n")[0]), (W + 2 - 3) // int(txt.split("stride=")[1].split("\n")[0]) + 1,
+                        (H + 2 - 3) // int(txt.split("stride=")[1].split("\n")[0]) + 1)
+    nheads = 0
+    for step in range(int(rng.integers(6, 18))):
+        c, w, h = cur
+        r = rng.random()
+        if r < 0.5:
+            conv_any()
+        elif r < 0.6 and min(w, h) >= 4:
+            kind = str(rng.choice(["maxpool", "avgpool", "max", "avg"]))
+            fs, st = int(rng.choice([2, 3, 3, 5])), int(rng.choice([1, 2, 2, 3]))
+            if w // st >= 1 and h // st >= 1:
+                emit("[%s]\nsize=%d\nstride=%d\n\n" % (kind, fs, st), (c, w // st, h // st))
+        elif r < 0.65 and max(w, h) <= 24:
+            st = int(rng.choice([2, 2, 3]))
+            emit("[upsample]\nstride=%d\n\n" % st, (c, w * st, h * st))
+        elif r < 0.7:
+            emit("[dropout]\nprobability=.2\n\n", cur)
+        elif r < 0.82:                                          # shortcut with any earlier layer of the same shape
+            cand = [i for i, sh in enumerate(shapes[:-1]) if sh == cur]
+            if cand:
+                i = cand[int(rng.integers(0, len(cand)))]
+                emit("[shortcut]\nfrom=%d\nactivation=%s\n\n" % (i - len(shapes), rng.choice(["linear", "leaky", "relu"])), cur)
+        elif r < 0.93:                                          # route: the previous tensor joined with earlier ones of the same plane size
+            # (ffcnn.c:178-183: a positive number is an absolute layer index, anything else counts back from here -- layer 0 has no
+            #  absolute name; the channels add up, the plane size is the last source's)
+            cand = [i for i, sh in enumerate(shapes[:-1]) if sh[1:] == cur[1:]]
+            k = int(rng.integers(0, min(3, len(cand)) + 1))
+            pick = [len(shapes) - 1] + [cand[int(j)] for j in rng.choice(len(cand), k, replace=False)] if cand and k else [[i for i in range(len(shapes)) if shapes[i][0] > 0][-1 - int(rng.integers(0, min(3, sum(1 for sh in shapes if sh[0] > 0))))]]
+            ctot = sum(shapes[i][0] for i in pick)
+            if ctot <= 200:
+                emit("[route]\nlayers = %s\n\n" % ",".join(str(i if (i > 0 and rng.random() < 0.5) else i - len(shapes)) for i in pick), (ctot, shapes[pick[0]][1], shapes[pick[0]][2]))
+        elif nheads < 2 and step > 3:
+            feat = len(shapes) - 1
+            emit("[convolutional]\nfilters=%d\nsize=1\nstride=1\npad=1\nactivation=linear\n\n" % (3 * (5 + classes)), (3 * (5 + classes), w, h))
+            emit("[yolo]\nmask = %s\nanchors = 4,6, 8,12, 16,14, 24,30, 40,36, 60,70\nclasses=%d\nignore_thresh = .6\nscale_x_y = 1.05\n\n" % (
+                rng.choice(["0,1,2", "3,4,5", "1,3,5"]), classes), (0, 0, 0))      # (a yolo layer has no output tensor: never a source)
+            nheads += 1
+            emit("[route]\nlayers = %d\n\n" % (feat if feat > 0 else feat - len(shapes)), shapes[feat])
+    c, w, h = cur
+    emit("[convolutional]\nfilters=%d\nsize=1\nstride=1\npad=1\nactivation=linear\n\n" % (3 * (5 + classes)), (3 * (5 + classes), w, h))
+    emit("[yolo]\nmask = 0,1,2\nanchors = 4,6, 8,12, 16,14, 24,30, 40,36, 60,70\nclasses=%d\nignore_thresh = .6\nscale_x_y = 1.05\n\n" % classes, (0, 0, 0))
+    return txt, (H, W)
+
+
 SEEDS = range(int(os.environ.get("FFCNN_FUZZ_SEED0", "0")), int(os.environ.get("FFCNN_FUZZ_SEED0", "0")) + int(os.environ.get("FFCNN_FUZZ_NETS", "12")))
 
 
+@pytest.mark.parametrize("grammar", ["mobile", "generic"])
 @pytest.mark.parametrize("seed", SEEDS)
-def test_random_nets_fused_vs_oracle(orc, tmp_path, seed):
+def test_random_nets_fused_vs_oracle(orc, tmp_path, seed, grammar):
     from ffcnn_amd import capi as F
     F.lib()
-    rng = np.random.default_rng(9100 + seed)
-    txt, (H, W) = random_cfg(rng)
+    rng = np.random.default_rng((9100 if grammar == "mobile" else 20000) + seed)
+    txt, (H, W) = random_cfg(rng) if grammar == "mobile" else random_generic_cfg(rng)
     cfg = str(tmp_path / "rnd.cfg")
     open(cfg, "w").write(txt)
     o = orc.Oracle(cfg=cfg, weights=None)
@@ -122,7 +214,7 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed):
         cands.append(o.candidates)
         boxes.append(o.boxes)
     # a candidate whose confidence sits within 2e-3 of the threshold may legitimately flip under the 1e-3 activation tolerance
-    edge = any(abs(float(c["score"]) - 0.55) < 2e-3 for cs in cands for c in cs)
+    edge = any(min(abs(float(c["score"]) - 0.55), abs(float(c["score"]) - 0.6)) < 2e-3 for cs in cands for c in cs)
     with F.Net(cfg, wpath) as n:
         assert n.layer_num == o.nlayers and np.array_equal(n.weights_host(), o.weights())
         for flags in (F.FFGPU.KEEP_ALL, F.FFGPU.KEEP_ALL | F.FFGPU.CONCURRENT, 0):
@@ -131,7 +223,8 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed):
                 ex.forward_host(frames)
                 dets = ex.read_dets()
                 nconv = sum(1 for i in range(o.nlayers) if o.layer(i).kind == 0)
-                assert ex.kernel_count < nconv + 4, "no fusion happened: %d launches for %d conv layers" % (ex.kernel_count, nconv)
+                if grammar == "mobile":
+                    assert ex.kernel_count < nconv + 4, "no fusion happened: %d launches for %d conv layers" % (ex.kernel_count, nconv)
                 seen = 0
                 if flags & F.FFGPU.KEEP_ALL:
                     for i in sorted(acts[0]):
@@ -145,7 +238,7 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed):
                         seen += 1
                         for f in range(B):
                             close(ex.read_layer(i, f), acts[f][i], "seed %d flags %d frame %d layer %d (%s)\n%s" % (seed, flags, f, i, ex.plan_text() if hasattr(ex, "plan_text") else "", ""))
-                    assert seen >= 3
+                    assert seen >= 3 or grammar != "mobile"
                 if not edge:
                     for f in range(B):
                         # more candidates than bbox_max (ffcnn.c:243,463: input bytes / 24): the reference keeps the first bbox_max in
