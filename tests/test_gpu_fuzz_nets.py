@@ -224,7 +224,7 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed, grammar):
                 dets = ex.read_dets()
                 nconv = sum(1 for i in range(o.nlayers) if o.layer(i).kind == 0)
                 if grammar == "mobile":
-                    assert ex.kernel_count < nconv + 4, "no fusion happened: %d launches for %d conv layers" % (ex.kernel_count, nconv)
+                    assert ex.kernel_count < o.nlayers, "no fusion happened: %d launches for %d layers (%d conv)" % (ex.kernel_count, o.nlayers, nconv)
                 seen = 0
                 if flags & F.FFGPU.KEEP_ALL:
                     for i in sorted(acts[0]):
