@@ -204,6 +204,8 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed, grammar):
     o.close()
     o = orc.Oracle(cfg=cfg, weights=wpath)
     B = int(rng.integers(1, 7))
+    if H * W <= 128 * 128 and rng.random() < 0.25:               # plans are functions of the batch: now and then a bigger, odd one
+        B = int(rng.choice([9, 17, 33, 64]))
     frames = rng.uniform(0, 1, (B, 3, H, W)).astype(np.float32)
     acts, cands, boxes = [], [], []
     for f in range(B):
