@@ -28,7 +28,7 @@ def draw(rng):
         ic = oc = groups = int(rng.choice([1, 2, 3, 8, 24, 32, 48, 96, 120, 136]))
         fs = int(rng.choice([3, 3, 5, 7]))
         stride = int(rng.choice([1, 1, 2, 3]))
-        pad = int(rng.choice([fs // 2, fs // 2, 0, 1]))
+        pad = int(rng.choice([fs // 2, fs // 2, fs // 2, 0, 1]))
         H, W = int(rng.integers(fs, 70)), int(rng.integers(fs, 90))
     elif kind == "dwbig":                                        # the streaming depthwise kernel's domain (W % 4 == 0, 40..512) and just outside it
         ic = oc = groups = int(rng.integers(1, 17))
@@ -86,6 +86,14 @@ def test_random_geometries_vs_oracle(orc, seed):
         for n in range(N):
             ref = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, groups, pad, stride, fs, act)
             check(got.reshape(oc, N, oh, ow)[:, n], ref.reshape(oc, oh, ow), what + " frame %d" % n)
+            if n == 0 and groups == ic == oc and fs == 5 and stride == 1 and pad == 2 and H >= 4 and W >= 4:
+                # conv-v6.c's 5x5 depthwise path (row oh - 2 without tap row 0, conv-v6.c:422-441) behind FFGPU_COMPAT_V6
+                dx, df = torch.from_numpy(x).cuda(), torch.from_numpy(f).cuda()
+                dy = torch.full((oc * N, oh, ow), float("nan"), device="cuda")
+                capi.groupconv_dev(dx.data_ptr(), df.data_ptr(), dy.data_ptr(), N, W, H, ic, groups, pad, stride, fs, oc, act, capi.FFGPU.COMPAT_V6, capi.FFGPU.K_AUTO, None)
+                torch.cuda.synchronize()
+                v6 = orc.groupconv(np.ascontiguousarray(xf[:, 0]), f, groups, pad, stride, fs, act, compat_v6=1)
+                check(dy.cpu().numpy().reshape(oc, N, oh, ow)[:, 0], v6.reshape(oc, oh, ow), what + " (COMPAT_V6)")
             if n == 0 and case % 3 == 0:                        # the conv.h drop-in itself (host pointers, one frame: conv.h:4-7)
                 check(capi.groupconv(np.ascontiguousarray(xf[:, 0]), f, groups, pad, stride, fs, act), ref.reshape(oc, oh, ow), what + " (conv.h drop-in)")
     assert len(picked) >= 3, picked                              # the draw reaches several kernels per seed
