@@ -24,6 +24,12 @@ def test_random_source_images(orc, seed):
             imgs = rng.integers(0, 256, (B, h, stride), dtype=np.uint8)
             mean = tuple(float(v) for v in rng.uniform(0, 128, 3)) if rng.random() < 0.5 else (0.0, 0.0, 0.0)
             norm = tuple(float(v) for v in rng.uniform(0.002, 0.02, 3)) if rng.random() < 0.5 else (1 / 255.0,) * 3
+            # the host net_input of the drop-in API (ffcnn_host.c) on the same image: bit-identical to the reference's arithmetic,
+            # including the scale factors net_forward will use (NET.s1 / s2)
+            o.set_input_image(np.ascontiguousarray(imgs[0]), w, h, mean, norm)
+            n.set_input_image(np.ascontiguousarray(imgs[0]), w, h, mean, norm)
+            assert np.array_equal(np.array(n.input), np.array(o.input)), "host net_input %dx%d" % (w, h)
+            assert (n.n.s1, n.n.s2) == (o.n.s1, o.n.s2), "scale %dx%d: %r vs %r" % (w, h, (n.n.s1, n.n.s2), (o.n.s1, o.n.s2))
             d = torch.from_numpy(imgs).cuda()
             with n.executor(B, F.FFGPU.KEEP_ALL) as ex:
                 ex.forward_bgr_dev(d.data_ptr(), w, h, mean, norm)
