@@ -1,0 +1,108 @@
+"""A seeded random WALK over the executor API: several executors of one net (different batch sizes and flags, each with its own
+captured graph), and a random sequence of calls -- host and device-resident forwards on different torch streams and buffers,
+source-scale changes, a record ring attached / restarted / detached, re-reads -- with the records checked against the oracle
+after every forward.  What it hunts: state that one call leaves behind for the next (the device parameter block, the ring
+counter, graph reuse across buffers, executors sharing a net's weights)."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import boxes_match
+
+pytestmark = pytest.mark.gpu
+
+SCALES = [(1, 1), (2, 1), (3, 2)]
+
+
+@pytest.fixture(scope="module")
+def pool(orc, test_image):
+    """8 frames x 3 source scales through the oracle: candidates (unscaled) and boxes (scaled by s1 / s2, ffcnn.c:519)"""
+    bgr, w, h = test_image
+    o = orc.Oracle()
+    o.set_input_image(bgr, w, h)
+    img = o.input.copy()
+    rng = np.random.default_rng(31)
+    fr = np.zeros((8, 3, 320, 320), np.float32)
+    fr[0] = img
+    fr[1] = np.roll(img, 53, axis=2)
+    fr[2] = img[:, ::-1, :]
+    fr[3] = np.clip(img + rng.normal(0, 0.1, img.shape), 0, 1)
+    fr[4] = 0.0
+    fr[5] = np.roll(img, -77, axis=1)
+    fr[6] = img[:, :, ::-1]
+    fr[7] = rng.uniform(0, 1, img.shape)
+    want = {}
+    for k in range(8):
+        for (s1, s2) in SCALES:
+            o.input[...] = fr[k]
+            o.n.s1, o.n.s2 = s1, s2
+            o.forward(0)
+            want[(k, s1, s2)] = (len(o.candidates), o.boxes)
+    o.close()
+    return fr, want
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FFCNN_FUZZ_SEED0", "0")), int(os.environ.get("FFCNN_FUZZ_SEED0", "0")) + int(os.environ.get("FFCNN_FUZZ_WALKS", "4"))))
+def test_random_api_walk(pool, seed):
+    import torch
+    from ffcnn_amd import capi as F
+    F.lib()
+    fr, want = pool
+    rng = np.random.default_rng(600 + seed)
+    streams = [None] + [torch.cuda.Stream() for _ in range(2)]
+    with F.Net() as n:
+        exs = []
+        for _ in range(3):
+            B = int(rng.choice([1, 2, 3, 5, 8]))
+            flags = int(rng.choice([0, F.FFGPU.CONCURRENT, F.FFGPU.HOST_DETS, F.FFGPU.NO_GRAPH, F.FFGPU.NO_FUSE]))
+            exs.append(dict(ex=n.executor(B, flags), B=B, scale=(1, 1), ring=None, k=0, flags=flags))
+        try:
+            for op in range(45):
+                e = exs[int(rng.integers(0, len(exs)))]
+                ex, B = e["ex"], e["B"]
+                r = rng.random()
+                if r < 0.15:
+                    e["scale"] = SCALES[int(rng.integers(0, 3))]
+                    ex.set_scale(*e["scale"])
+                    continue
+                if r < 0.25:                                    # attach (or restart) a ring of 2-4 slots, or detach it
+                    if e["ring"] is not None and rng.random() < 0.4:
+                        ex.set_ring(None, 0)
+                        e["ring"] = None
+                    else:
+                        slots = int(rng.integers(2, 5))
+                        nbytes = ex.dets_dev()[1]
+                        e["ring"] = (torch.zeros((slots, nbytes), dtype=torch.uint8, device="cuda"), slots)
+                        ex.set_ring(e["ring"][0].data_ptr(), slots)
+                        e["k"] = 0
+                    continue
+                pick = [int(v) for v in rng.integers(0, 8, B)]
+                frames = np.ascontiguousarray(fr[pick])
+                st = streams[int(rng.integers(0, 3))]
+                if rng.random() < 0.5:
+                    ex.forward_host(frames)
+                else:
+                    buf = torch.from_numpy(frames).cuda()       # a fresh device buffer every time
+                    if st is not None:
+                        st.wait_stream(torch.cuda.current_stream())
+                    ex.forward_dev(buf.data_ptr(), st.cuda_stream if st is not None else None)
+                    (st or torch.cuda.current_stream()).synchronize()
+                dets = ex.read_dets()
+                s1, s2 = e["scale"]
+                for f in range(B):
+                    nc, bx = want[(pick[f], s1, s2)]
+                    assert dets[f]["ncand"] == nc, "op %d frame %d (source %d): %d candidates, oracle %d" % (op, f, pick[f], dets[f]["ncand"], nc)
+                    boxes_match(ex.boxes(f, dets), bx, "op %d executor batch %d flags %d frame %d scale %r" % (op, B, e["flags"], f, e["scale"]))
+                if e["ring"] is not None:                       # the same records sit in slot k % slots of the ring
+                    ring, slots = e["ring"]
+                    torch.cuda.synchronize()
+                    rec = np.frombuffer(ring[e["k"] % slots].cpu().numpy().tobytes(), F.DETS_DTYPE)
+                    assert np.array_equal(rec["count"], dets["count"]) and np.array_equal(rec["ncand"], dets["ncand"]), "ring slot %d" % (e["k"] % slots)
+                    for f in range(B):
+                        assert np.array_equal(rec[f]["box"][:rec[f]["count"]], dets[f]["box"][:dets[f]["count"]])
+                    e["k"] += 1
+                assert ex.graph_captures <= 1
+        finally:
+            for e in exs:
+                e["ex"].close()
