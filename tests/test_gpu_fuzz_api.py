@@ -106,3 +106,45 @@ def test_random_api_walk(pool, seed):
         finally:
             for e in exs:
                 e["ex"].close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FFCNN_FUZZ_SEED0", "0")), int(os.environ.get("FFCNN_FUZZ_SEED0", "0")) + int(os.environ.get("FFCNN_FUZZ_WALKS", "4"))))
+def test_random_node_walk(pool, seed):
+    """the C node path (ffgpu_node_*: shards, per-rank executors, gather offsets, pipelined slots) on one device through the
+    loopback transport: random rank counts, uneven totals, depths 1-4, scale changes, synchronous forwards mixed with
+    submit / wait in any legal order -- every step's records in global frame order against the oracle"""
+    from ffcnn_amd import capi as F
+    F.lib()
+    fr, want = pool
+    rng = np.random.default_rng(900 + seed)
+    ranks = int(rng.integers(1, 5))
+    total = int(rng.integers(ranks, 11))
+    depth = int(rng.integers(1, 5))
+    flags = int(rng.choice([0, F.FFGPU.CONCURRENT]))
+    with F.Net() as n, F.Node(n, ranks, total, exec_flags=flags, node_flags=F.Node.LOOPBACK | F.Node.DEPTH(depth)) as nd:
+        scale = (1, 1)
+        inflight = []                                           # (ticket, pick, scale at submit)
+
+        def check(dets, pick, sc, what):
+            for f in range(total):
+                nc, bx = want[(pick[f], sc[0], sc[1])]
+                assert dets[f]["ncand"] == nc, "%s frame %d: %d candidates, oracle %d" % (what, f, dets[f]["ncand"], nc)
+                boxes_match(dets[f]["box"][:dets[f]["count"]], bx, "%s ranks %d total %d depth %d frame %d" % (what, ranks, total, depth, f))
+
+        for op in range(14):
+            r = rng.random()
+            if r < 0.15 and not inflight:                       # (the scale belongs to the node: changed between steps only)
+                scale = SCALES[int(rng.integers(0, 3))]
+                nd.set_scale(*scale)
+                continue
+            pick = [int(v) for v in rng.integers(0, 8, total)]
+            frames = np.ascontiguousarray(fr[pick])
+            if r < 0.45 and not inflight:
+                check(nd.forward_host(frames), pick, scale, "op %d forward_host" % op)
+            elif len(inflight) < depth and (r < 0.8 or not inflight):
+                inflight.append((nd.submit(frames), pick, scale))
+            else:
+                t, pk, sc = inflight.pop(0)
+                check(nd.wait(t), pk, sc, "op %d wait(%d)" % (op, t))
+        for t, pk, sc in inflight:
+            check(nd.wait(t), pk, sc, "drain wait(%d)" % t)
