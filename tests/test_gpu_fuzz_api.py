@@ -148,3 +148,63 @@ def test_random_node_walk(pool, seed):
                 check(nd.wait(t), pk, sc, "op %d wait(%d)" % (op, t))
         for t, pk, sc in inflight:
             check(nd.wait(t), pk, sc, "drain wait(%d)" % t)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FFCNN_FUZZ_SEED0", "0")), int(os.environ.get("FFCNN_FUZZ_SEED0", "0")) + int(os.environ.get("FFCNN_FUZZ_WALKS", "4"))))
+def test_random_lifecycle_walk(pool, test_image, seed):
+    """object lifetimes: several NETs (native geometry and others) and their executors created, used through both API levels
+    (net_input + net_forward of the drop-in API, batched executors) and destroyed in random order -- a net may be freed
+    between two forwards of another one, and an executor whose net has been freed is an orphan: it refuses to run (loudly)
+    and can still be destroyed, at any later point"""
+    import ctypes as C
+    from ffcnn_amd import capi as F
+    F.lib()
+    fr, want = pool
+    bgr, w, h = test_image
+    rng = np.random.default_rng(1300 + seed)
+    nets, exs = [], []
+    try:
+        for op in range(30):
+            r = rng.random()
+            if r < 0.2 and len(nets) < 4:
+                geo = [(0, 0), (0, 0), (640, 448), (96, 64)][int(rng.integers(0, 4))]
+                nets.append(dict(n=F.Net(w=geo[0], h=geo[1]), geo=geo))
+            elif r < 0.4 and nets:
+                e = nets[int(rng.integers(0, len(nets)))]
+                if e["geo"] == (0, 0):
+                    B = int(rng.choice([1, 2, 4]))
+                    exs.append(dict(ex=e["n"].executor(B, int(rng.choice([0, F.FFGPU.CONCURRENT]))), B=B, net=e, orphan=False))
+            elif r < 0.5 and nets:
+                e = nets.pop(int(rng.integers(0, len(nets))))
+                e["n"].close()
+                for x in exs:
+                    if x["net"] is e:
+                        x["orphan"] = True
+            elif r < 0.6 and exs:
+                exs.pop(int(rng.integers(0, len(exs))))["ex"].close()
+            elif r < 0.8 and exs:
+                e = exs[int(rng.integers(0, len(exs)))]
+                pick = [int(v) for v in rng.integers(0, 8, e["B"])]
+                if e["orphan"]:                                 # (straight through the C-ABI: the Python wrapper would look at the freed NET)
+                    two = np.ascontiguousarray(fr[pick])
+                    assert F.lib().ffgpu_exec_forward_host(e["ex"].h, two.ctypes.data_as(C.POINTER(C.c_float))) < 0 and "has been freed" in F.last_error()
+                    continue
+                e["ex"].set_scale(1, 1)
+                e["ex"].forward_host(np.ascontiguousarray(fr[pick]))
+                dets = e["ex"].read_dets()
+                for f in range(e["B"]):
+                    boxes_match(e["ex"].boxes(f, dets), want[(pick[f], 1, 1)][1], "op %d executor frame %d" % (op, f))
+            elif nets:
+                e = nets[int(rng.integers(0, len(nets)))]
+                if e["geo"] == (0, 0):                          # the drop-in path on the native geometry: test.bmp -> the golden boxes
+                    e["n"].set_input_image(bgr, w, h)
+                    e["n"].forward()
+                    assert len(e["n"].boxes) == 3, "op %d: net_forward found %d boxes" % (op, len(e["n"].boxes))
+                else:
+                    e["n"].input[...] = 0.25
+                    e["n"].forward()
+    finally:
+        for e in exs:
+            e["ex"].close()
+        for e in nets:
+            e["n"].close()
