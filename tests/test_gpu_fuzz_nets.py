@@ -219,13 +219,14 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed, grammar):
     edge = any(min(abs(float(c["score"]) - 0.55), abs(float(c["score"]) - 0.6)) < 2e-3 for cs in cands for c in cs)
     with F.Net(cfg, wpath) as n:
         assert n.layer_num == o.nlayers and np.array_equal(n.weights_host(), o.weights())
-        for flags in (F.FFGPU.KEEP_ALL, F.FFGPU.KEEP_ALL | F.FFGPU.CONCURRENT, 0):
+        extra = int(rng.choice([F.FFGPU.SPLIT2, F.FFGPU.SPLIT2 | F.FFGPU.CONCURRENT, F.FFGPU.HOST_DETS, F.FFGPU.NO_GRAPH | F.FFGPU.CONCURRENT, F.FFGPU.NO_FUSE]))
+        for flags in (F.FFGPU.KEEP_ALL, F.FFGPU.KEEP_ALL | F.FFGPU.CONCURRENT, 0, extra):
             with n.executor(B, flags) as ex:
                 ex.set_scale(1, 1)
                 ex.forward_host(frames)
                 dets = ex.read_dets()
                 nconv = sum(1 for i in range(o.nlayers) if o.layer(i).kind == 0)
-                if grammar == "mobile":
+                if grammar == "mobile" and not (flags & (F.FFGPU.NO_FUSE | F.FFGPU.SPLIT2)):      # (a split executor runs two half-batch chains)
                     assert ex.kernel_count < o.nlayers, "no fusion happened: %d launches for %d layers (%d conv)" % (ex.kernel_count, o.nlayers, nconv)
                 seen = 0
                 if flags & F.FFGPU.KEEP_ALL:
