@@ -452,6 +452,14 @@ def main():
         roof = kernel_roofline(torch, capi, stream)
         roof_pw = pw_roofline(torch, capi, stream)
         torch.cuda.synchronize()
+    else:
+        # N > 1 (or --no-kernel-roofline): the same device state by other means -- ~40 ms of untimed forwards in front of the
+        # W warm-up steps, on every rank.  Without them a short run at N > 1 is measured on a device that is still ramping
+        # while the N = 1 run (which has just done its roofline launches) is not: 173 k against 184 k frames/s per GPU at 20
+        # steps, a 6 % "scaling loss" that is measurement order and nothing else.
+        for i in range(max(S, 128 // MS // S * S)):
+            exs[i % S].forward_dev(xs[i % K_in].data_ptr(), streams[i % S].cuda_stream)
+        torch.cuda.synchronize()
     # warm-up and timed steps are numbered from 0 each, so both start on a fresh group and end with a flush
     nl_warm, nl = -(-args.warmup // MS), -(-args.steps // MS)    # launches (a launch = MS steps; a ragged last one still does MS)
     restart()
