@@ -208,3 +208,35 @@ def test_random_lifecycle_walk(pool, test_image, seed):
             e["ex"].close()
         for e in nets:
             e["n"].close()
+
+
+def test_no_device_or_host_memory_leak(pool):
+    """200 x (net_load, two executors, forwards through both API levels, destroy everything): the device's free memory and the
+    process's resident set come back to where they were (a production host reloads models and re-plans executors for years)"""
+    import resource
+    import torch
+    from ffcnn_amd import capi as F
+    F.lib()
+    fr, want = pool
+
+    def cycle(k):
+        with F.Net() as n:
+            with n.executor(1 + k % 4, F.FFGPU.CONCURRENT if k % 2 else 0) as ex, n.executor(2, F.FFGPU.HOST_DETS) as ex2:
+                ex.forward_host(np.ascontiguousarray(fr[:1 + k % 4]))
+                ex2.forward_host(np.ascontiguousarray(fr[:2]))
+                ex.read_dets()
+            n.input[...] = fr[0]
+            n.forward()
+
+    for k in range(10):                                         # allocator pools, code objects, RCCL-free paths settle first
+        cycle(k)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    for k in range(200):
+        cycle(k)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert free0 - free1 < 64 << 20, "device memory: %.1f MB gone after 200 load / plan / run / free cycles" % ((free0 - free1) / 2**20)
+    assert rss1 - rss0 < 256 << 10, "host memory: peak RSS grew by %.1f MB over 200 cycles" % ((rss1 - rss0) / 1024)

@@ -13,6 +13,32 @@ from test_gpu_parity import _write_random_weights, boxes_match, close
 pytestmark = pytest.mark.gpu
 
 
+def boxes_match_near_ties(got, want, what):
+    """boxes_match, except that boxes whose scores agree to 2e-6 may come in either order: the reference sorts by score
+    (ffcnn.c:301), random nets produce thousands of boxes with scores within an ulp of each other, and a last-bit difference
+    in a score swaps two neighbours without being an error.  Every box must have its partner (class, score within 1e-4,
+    corners within 0.05) at most 8 places away."""
+    try:
+        boxes_match(got, want, what)
+        return
+    except AssertionError:
+        pass
+    assert len(got) == len(want), "%s: %d vs %d boxes" % (what, len(got), len(want))
+    used = np.zeros(len(want), bool)
+    for i, g in enumerate(got):
+        lo, hi = max(0, i - 8), min(len(want), i + 9)
+        ok = -1
+        for j in range(lo, hi):
+            w = want[j]
+            if (not used[j] and int(g["type"]) == int(w["type"]) and abs(float(g["score"]) - float(w["score"])) <= 1e-4 and
+                    all(abs(float(g[k]) - float(w[k])) <= 0.05 for k in ("x1", "y1", "x2", "y2"))):
+                ok = j
+                break
+        assert ok >= 0, "%s: box %d %r has no partner near its place" % (what, i, g)
+        assert ok == i or abs(float(want[ok]["score"]) - float(want[i]["score"])) <= 2e-6, "%s: box %d moved %d places across a real score gap" % (what, i, ok - i)
+        used[ok] = True
+
+
 def conv(filters, size, stride, act, groups=1, bn=1):
     s = "[convolutional]\n"
     if groups > 1:
@@ -253,7 +279,7 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed, grammar):
                         # random weights can drive exp(tw) to 1e10 pixels: boxes are compared where the 0.05-pixel tolerance
                         # means something (every candidate within +-2000 pixels); the full list, not the 128 of the record
                         if all(abs(float(c[k])) < 2000 for c in cands[f] for k in ("x1", "y1", "x2", "y2")):
-                            boxes_match(ex.read_boxes(f), boxes[f], "seed %d flags %d frame %d boxes" % (seed, flags, f))
+                            boxes_match_near_ties(ex.read_boxes(f), boxes[f], "seed %d flags %d frame %d boxes" % (seed, flags, f))
     o.close()
 
 
