@@ -127,10 +127,13 @@ def random_generic_cfg(rng):
     back over several layers, routes joining one to three earlier tensors, one to three yolo heads.  Shapes are tracked so that
     every join is legal; -> (text, (H, W))."""
     W, H = int(rng.choice([32, 64, 96, 128])), int(rng.choice([32, 64, 96]))
+    if rng.random() < 0.3:                                      # a cfg's own size is taken as it is (ffcnn.c:131-134): any integers
+        W, H = int(rng.integers(17, 131)), int(rng.integers(17, 101))
+    CIN = int(rng.choice([3, 3, 3, 1, 4]))
     classes = int(rng.choice([1, 3]))
-    txt = "[net]\nwidth=%d\nheight=%d\nchannels=3\n\n" % (W, H)
+    txt = "[net]\nwidth=%d\nheight=%d\nchannels=%d\n\n" % (W, H, CIN)
     shapes = []                                                 # per layer: (c, w, h)
-    cur = (3, W, H)
+    cur = (CIN, W, H)
 
     def emit(t, shape):
         nonlocal txt, cur
@@ -209,7 +212,7 @@ def random_generic_cfg(rng):
     c, w, h = cur
     emit("[convolutional]\nfilters=%d\nsize=1\nstride=1\npad=1\nactivation=linear\n\n" % (3 * (5 + classes)), (3 * (5 + classes), w, h))
     emit("[yolo]\nmask = 0,1,2\nanchors = 4,6, 8,12, 16,14, 24,30, 40,36, 60,70\nclasses=%d\nignore_thresh = .6\nscale_x_y = 1.05\n\n" % classes, (0, 0, 0))
-    return txt, (H, W)
+    return txt, (H, W, CIN)
 
 
 SEEDS = range(int(os.environ.get("FFCNN_FUZZ_SEED0", "0")), int(os.environ.get("FFCNN_FUZZ_SEED0", "0")) + int(os.environ.get("FFCNN_FUZZ_NETS", "12")))
@@ -221,7 +224,8 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed, grammar):
     from ffcnn_amd import capi as F
     F.lib()
     rng = np.random.default_rng((9100 if grammar == "mobile" else 20000) + seed)
-    txt, (H, W) = random_cfg(rng) if grammar == "mobile" else random_generic_cfg(rng)
+    txt, hw = random_cfg(rng) if grammar == "mobile" else random_generic_cfg(rng)
+    H, W, CIN = hw if len(hw) == 3 else (hw[0], hw[1], 3)
     cfg = str(tmp_path / "rnd.cfg")
     open(cfg, "w").write(txt)
     o = orc.Oracle(cfg=cfg, weights=None)
@@ -232,7 +236,7 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed, grammar):
     B = int(rng.integers(1, 7))
     if H * W <= 128 * 128 and rng.random() < 0.25:               # plans are functions of the batch: now and then a bigger, odd one
         B = int(rng.choice([9, 17, 33, 64]))
-    frames = rng.uniform(0, 1, (B, 3, H, W)).astype(np.float32)
+    frames = rng.uniform(0, 1, (B, CIN, H, W)).astype(np.float32)
     acts, cands, boxes = [], [], []
     for f in range(B):
         o.input[...] = frames[f]
