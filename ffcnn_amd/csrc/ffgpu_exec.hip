@@ -1432,7 +1432,7 @@ extern "C" float ffgpu_dwpw_dev(const float *d_in, const float *d_wd, const floa
 // -------------------------------------------------------------------------- conv.h drop-in (host pointers)
 // Literal replacement for a conv-vN.c object: stages through device scratch that
 // grows on demand and is kept for the life of the process (one per thread).
-struct HostConvScratch { float *in = nullptr, *filt = nullptr, *out = nullptr; size_t in_n = 0, filt_n = 0, out_n = 0; };
+struct HostConvScratch { float *in = nullptr, *filt = nullptr, *out = nullptr; size_t in_n = 0, filt_n = 0, out_n = 0; int dev = -1; };
 
 static int grow(float **p, size_t *have, size_t need)
 {
@@ -1456,6 +1456,13 @@ extern "C" void groupconv(float *in, float *filt, float *out,
     const size_t n_f = (size_t)fn * ((((size_t)fs * fs * (ic / ig) + 3) & ~(size_t)3) + 4);
     const char *env = getenv("FFCNN_COMPAT_V6");
     const int flags = (env && atoi(env)) ? FFGPU_COMPAT_V6 : 0;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (sc.dev != cur) {                          // the thread moved to another GPU (ffgpu_set_device): the buffers stay behind
+        (void)hipFree(sc.in); (void)hipFree(sc.filt); (void)hipFree(sc.out);
+        sc = HostConvScratch();
+        sc.dev = cur;
+    }
     int rc = grow(&sc.in, &sc.in_n, n_in) || grow(&sc.filt, &sc.filt_n, n_f) || grow(&sc.out, &sc.out_n, n_out);
     if (!rc) rc = hipMemcpy(sc.in, in, n_in * sizeof(float), hipMemcpyHostToDevice) != hipSuccess
                || hipMemcpy(sc.filt, filt, n_f * sizeof(float), hipMemcpyHostToDevice) != hipSuccess;
