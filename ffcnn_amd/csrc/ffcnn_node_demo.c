@@ -53,7 +53,9 @@ int main(int argc, char **argv)
         for (size_t row = 0; row < (size_t)l0->c * l0->h; row++)
             for (int x = 0; x < l0->w; x++)
                 frames[k * fl + row * l0->w + (size_t)((x + k) % l0->w)] = l0->data[row * l0->w + x];
-    const int depth = 4;                                             /* steps in flight */
+    int depth = getenv("FFCNN_NODE_DEPTH") ? atoi(getenv("FFCNN_NODE_DEPTH")) : 8;   /* steps in flight (1..8) */
+    if (depth < 1) depth = 1;
+    if (depth > 8) depth = 8;
     ffgpu_node *node = ffgpu_node_create(net, ndev, NULL, batch, FFGPU_CONCURRENT, FFGPU_NODE_DEPTH(depth));
     if (!node) { fprintf(stderr, "ffgpu_node_create failed: %s\n", ffgpu_last_error()); return 1; }
     ffgpu_node_set_scale(node, net->s1, net->s2);
