@@ -99,6 +99,7 @@ struct ffgpu_netdev {
     size_t weight_bytes = 0;
     int    device = 0;
     ffgpu_exec *exec1 = nullptr;
+    void  *pinned_input = nullptr;     // layer_list[0].data registered with the driver (net_forward's H2D copy is then a DMA, not a staged copy)
 };
 
 struct ffgpu_exec {
@@ -1226,6 +1227,7 @@ extern "C" void ffgpu_netdev_destroy(void *p)
     ffgpu_netdev *dev = (ffgpu_netdev *)p;
     if (!dev) return;
     if (dev->exec1) { ffgpu_exec_destroy(dev->exec1); dev->exec1 = nullptr; }
+    if (dev->pinned_input) { (void)hipHostUnregister(dev->pinned_input); dev->pinned_input = nullptr; }    // (net_free frees it right after)
     // executors the caller still holds outlive the net as orphans: their steps point into d_weights and the layer table,
     // so they wait for their streams here and from now on refuse to run (alive()); ffgpu_exec_destroy still frees them
     std::vector<ffgpu_exec *> left;
@@ -1247,8 +1249,13 @@ extern "C" int ffgpu_netdev_forward1(NET *net, void *p, int profile)
 {
     ffgpu_netdev *dev = (ffgpu_netdev *)p;
     if (!dev->exec1) {
-        dev->exec1 = ffgpu_exec_create(net, 1, 0);
+        // one frame at a time is latency: the records come back through the pinned host mirror (no device-to-host copy), and the
+        // input tensor the application fills is page-locked so that its upload is one DMA (best effort: a failure only costs time)
+        dev->exec1 = ffgpu_exec_create(net, 1, FFGPU_HOST_DETS);
         if (!dev->exec1) return -1;
+        const LAYER *l0 = net->layer_list;
+        if (l0->data && hipHostRegister(l0->data, sizeof(float) * (size_t)l0->c * l0->h * l0->w, hipHostRegisterDefault) == hipSuccess) dev->pinned_input = l0->data;
+        else (void)hipGetLastError();
     }
     ffgpu_exec *ex = dev->exec1;
     ex->s1 = net->s1 ? net->s1 : 1;
