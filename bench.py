@@ -226,6 +226,122 @@ def pw_roofline(torch, capi, stream):
             "workload": "pw1x1 256->512 20x20 batch 256 fp32 (BASELINE config[2])"}
 
 
+def node_line(args, ngpus):
+    """`bench.py --node` in a child process (its own HIP context on all devices; a hang or crash there costs only this entry)."""
+    env = {k: v for k, v in os.environ.items()
+           if not (k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "GROUP_WORLD_SIZE",
+                         "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") or k.startswith("TORCHELASTIC") or k.startswith("TORCH_NCCL"))}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--node", "--gpus", str(ngpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--depth", str(max(1, min(args.streams, 8)))]
+    if args.global_batch > 0:
+        cmd += ["--global-batch", str(args.global_batch)]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+        d = json.loads(lines[-1])
+        return {k: d[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "host", "config")}
+    except Exception as e:                                      # noqa: BLE001 -- an extra: never costs the main line
+        return {"error": repr(e)[:400]}
+
+
+def run_node(args):
+    """The same job through the C node API (include/ffcnn_hip.h ffgpu_node_*), as a C host program would drive it: one process, one
+    thread, N devices; per step ffgpu_node_submit (forward on every device, packed gather of the records over RCCL, one D2H) and
+    ffgpu_node_wait (records of the whole step in host memory), `--depth` steps in flight.  torch only fills the input buffers."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("--node is one process for all GPUs: do not launch it under torchrun")
+    import torch
+    from ffcnn_amd import capi
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    N = args.gpus
+    if torch.cuda.device_count() < N:
+        raise SystemExit("--gpus %d but %d devices visible" % (N, torch.cuda.device_count()))
+    strong = args.global_batch > 0
+    G = args.global_batch if strong else FRAMES_PER_GPU * N
+    D = max(1, min(args.depth, 8))
+    torch.cuda.set_device(0)
+    capi.lib().ffgpu_set_device(0)
+    os.environ.setdefault("FFGPU_BRANCH", "0" if D > 1 else "1")
+    net = capi.Net()
+    nd = capi.Node(net, N, G, exec_flags=capi.FFGPU.CONCURRENT if D >= 3 else 0, node_flags=capi.Node.DEPTH(D))
+    nd.set_scale(640, 320)
+    # synthetic frames: the same global stream as the torchrun job (seed 1236, frame 0 = letterboxed test.bmp); every slot of
+    # every device holds its own batch, resident in HBM before the timed region (D x 78.6 MB per device > the Infinity Cache)
+    img = check = None
+    try:
+        bgr, w, h = capi.load_bmp(os.path.join(ROOT, "data", "test.bmp"))
+        net.set_input_image(bgr, w, h)
+        img = torch.from_numpy(net.input.copy())
+        check = json.load(open(os.path.join(ROOT, "tests", "golden", "boxes.json")))["net_320x320_v0"]["boxes"]
+    except Exception as e:                                      # noqa: BLE001
+        print("bench: golden check unavailable: %r" % (e,), file=sys.stderr)
+    fl = 3 * 320 * 320
+    for slot in range(D):
+        g = torch.Generator(device="cuda:0").manual_seed(1236 + slot)
+        for r in range(N):
+            lo, hi, dev = nd.shard(r)
+            with torch.cuda.device(dev):
+                view = torch.as_tensor(DevBuf(nd.input_slot_dev(r, slot), (hi - lo) * fl * 4, "<f4"), device="cuda:%d" % dev).view(hi - lo, 3, 320, 320)
+                for c0 in range(lo, hi, 64):
+                    cn = min(64, hi - c0)
+                    chunk = torch.rand((cn, 3, 320, 320), device="cuda:0", generator=g)
+                    view[c0 - lo:c0 - lo + cn] = chunk.to("cuda:%d" % dev)
+                    del chunk
+                if r == 0 and img is not None:
+                    view[0] = img.to("cuda:%d" % dev)
+    for d in range(N):
+        torch.cuda.synchronize(d)
+    recs = np.zeros(G, capi.DETS_DTYPE)
+
+    def run(nsteps):
+        inflight = []
+        for _ in range(nsteps):
+            if len(inflight) == D:
+                nd.wait_into(inflight.pop(0), recs)
+            inflight.append(nd.submit())
+        for t in inflight:
+            nd.wait_into(t, recs)
+
+    pre = max(D, 128 // D * D)                                  # the device's sustained clock state (see main(): ~40 ms of forwards)
+    run(pre)
+    run(args.warmup)
+    for d in range(N):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    run(args.steps)
+    for d in range(N):
+        torch.cuda.synchronize(d)
+    dt = time.perf_counter() - t0
+    # frame 0 of the LAST step sits in slot (steps - 1) % D ... every slot's frame 0 is the test image
+    ok = None
+    if check is not None:
+        got = recs[0]["box"][: recs[0]["count"]]
+        ok = bool(len(got) == len(check) and all(
+            int(a["type"]) == int(b["type"]) and abs(float(a["score"]) - float(b["score"])) < 1e-4 and
+            max(abs(float(a[k]) - float(b[k])) for k in ("x1", "y1", "x2", "y2")) < 0.05 for a, b in zip(got, check)))
+    out = {"metric": "frames/sec yolo-fastest-1.1 @320x320 batch-64 per GPU (full forward: conv stack + YOLO decode + NMS, boxes in host memory)"
+                     if not strong else "frames/sec yolo-fastest-1.1 @320x320 global batch %d sharded over the GPUs (full forward + boxes in host memory)" % G,
+           "value": round(G * args.steps / dt, 1), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "host": "C node API: one process, one host thread, ffgpu_node_submit / ffgpu_node_wait over include/ffcnn_hip.h",
+           "config": {"workload": "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[%d])" % (4 if strong else 3),
+                      "frames_per_gpu": G // N, "global_batch": G, "parallelism": "dp%d" % N, "steps_in_flight": D,
+                      "exchange": "none (one device: the NMS kernel writes the records into pinned host memory)" if N == 1 else
+                                  "ncclBroadcast of the weights at create; per step one grouped ncclSend/ncclRecv of the packed records per peer + one D2H",
+                      "untimed_forwards_before_t0": pre + args.warmup,
+                      "boxes_match_reference_golden_frame0": ok}}
+    nd.close()
+    net.close()
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,7 +365,14 @@ def main():
     ap.add_argument("--global-batch", type=int, default=int(os.environ.get("FFCNN_BENCH_GLOBAL_BATCH", "0")),
                     help="strong scaling (BASELINE config[4]: 256): a step is this many frames in total, cut into contiguous "
                          "shards of global/N per GPU; 0 = weak scaling, 64 frames per GPU")
+    ap.add_argument("--node", action="store_true",
+                    help="the C host path: ONE process drives all --gpus devices through ffgpu_node_create / submit / wait (RCCL broadcast of "
+                         "the weights, packed gather of the records); not under torchrun")
+    ap.add_argument("--depth", type=int, default=4, help="--node: steps in flight (FFGPU_NODE_DEPTH; one executor per slot and device)")
+    ap.add_argument("--no-node-line", action="store_true", help="skip the extra c_node_api measurement (a child `bench.py --node` run by rank 0 after the timed job)")
     args = ap.parse_args()
+    if args.node:
+        return run_node(args)
 
     import torch
     import torch.distributed as dist
@@ -432,9 +555,11 @@ def main():
     # One HIP graph per executor, captured on its first forward and valid for every input buffer (the input pointer travels
     # through the executor's device parameter block): every (executor, input set) pair runs once here anyway, so nothing of
     # a first use -- graph capture, page mapping of a fresh buffer -- can land inside the timed region
+    untimed = 0                                                 # forwards (launches of the whole net) enqueued before t0, reported in the line
     for k in range(max(K_in, S)):
         for j in range(S):
             exs[j].forward_dev(xs[k % K_in].data_ptr(), streams[j].cuda_stream)
+            untimed += 1
     torch.cuda.synchronize()
     assert all(e.graph_captures == 1 for e in exs)
     if gather_mode:                                             # ... and RCCL sets its communicator up on the first collective
@@ -459,12 +584,14 @@ def main():
         # steps, a 6 % "scaling loss" that is measurement order and nothing else.
         for i in range(max(S, 128 // MS // S * S)):
             exs[i % S].forward_dev(xs[i % K_in].data_ptr(), streams[i % S].cuda_stream)
+            untimed += 1
         torch.cuda.synchronize()
     # warm-up and timed steps are numbered from 0 each, so both start on a fresh group and end with a flush
     nl_warm, nl = -(-args.warmup // MS), -(-args.steps // MS)    # launches (a launch = MS steps; a ragged last one still does MS)
     restart()
     for i in range(nl_warm):
         step(i)
+    untimed += nl_warm
     flush(nl_warm)
     fence()
     restart()
@@ -508,6 +635,9 @@ def main():
                        "frames_per_gpu": B, "global_batch": G, "parallelism": "dp%d" % world,
                        "steps_per_launch": MS, "frames_per_launch": Bx,
                        "input_sets": K_in,
+                       "untimed_forwards_before_t0": untimed,
+                       "untimed_kernel_launches_before_t0": ("~270 single-kernel launches of the config[1] / config[2] roofline measurements (~100 ms) between "
+                                                             "set-up and the warm-up steps" if roof is not None else "none besides the forwards"),
                        "launches_per_step": ex.kernel_count, "arena_MB": round(ex.arena_bytes / 2**20, 1),
                        "executors": S, "pipelining": "%d executors on %d streams take the batches in turn%s" % (S, S, ", each split in two half-batch chains" if args.split else ""), "gather": ("RCCL gather of %d steps' records (packed: %d bytes per step and rank) + D2H on a side stream, overlapped with the next steps" % (M, pbytes)) if gather_mode else "records written to pinned host memory by the NMS kernel",
                        "graph_captures_per_executor": max(e.graph_captures for e in exs),
@@ -563,6 +693,12 @@ def main():
     net.close()
     if world > 1 or args.force_gather:
         dist.destroy_process_group()
+    if out is not None and not args.no_node_line:
+        # north_star's host path -- plain C over the C-ABI, one process for all GPUs -- measured beside the torchrun job: rank 0
+        # (alone by now: the process group is gone, the other ranks are leaving) runs `bench.py --node` on the same N devices
+        del xs, x
+        torch.cuda.empty_cache()
+        out["c_node_api"] = node_line(args, world)
     if out is not None:
         # the ONE JSON line is the last thing on stdout: RCCL's version banner sits in the C library's stdout buffer
         # until it is flushed

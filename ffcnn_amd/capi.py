@@ -463,11 +463,21 @@ class Node:
         t = lib().ffgpu_node_submit(self.h, frames.ctypes.data_as(f32p) if frames is not None else None)
         if t < 0:
             raise RuntimeError("ffgpu_node_submit failed: %s" % last_error())
+        if frames is not None:
+            self._held[t] = frames                              # the upload is asynchronous: the host frames live until wait(t)
         return t
 
     def wait(self, ticket):
         out = np.zeros(self.total, DETS_DTYPE)
         _check(lib().ffgpu_node_wait(self.h, ticket, out.ctypes.data), "ffgpu_node_wait")
+        self._held.pop(ticket, None)
+        return out
+
+    def wait_into(self, ticket, out):
+        """as wait(), into a caller-owned DETS_DTYPE array of `total` records"""
+        assert out.dtype == DETS_DTYPE and len(out) == self.total and out.flags["C_CONTIGUOUS"]
+        _check(lib().ffgpu_node_wait(self.h, ticket, out.ctypes.data), "ffgpu_node_wait")
+        self._held.pop(ticket, None)
         return out
 
     def input_slot_dev(self, rank, slot):
@@ -475,6 +485,7 @@ class Node:
 
     def __init__(self, net, ndev, global_batch, devices=None, exec_flags=0, node_flags=0):
         self.net, self.ndev, self.total = net, ndev, global_batch
+        self._held = {}
         dv = (C.c_int * ndev)(*devices) if devices is not None else None
         self.h = lib().ffgpu_node_create(net.p, ndev, dv, global_batch, exec_flags, node_flags)
         if not self.h:

@@ -295,6 +295,10 @@ NET *net_load(char *cfg_path, char *weights_path, int inputw, int inputh)
 
     ext->dev = ffgpu_netdev_create(net);
     if (!ext->dev) { net_free(net); return NULL; }          /* no device, no net: error text already set */
+    /* the tensor the application fills (net_input, or its own writes) moves into page-locked memory of the HIP runtime: net_forward
+     * uploads it with one DMA.  Best effort -- a failure leaves the calloc'd tensor in place and only costs time. */
+    ext->pinned_input = getenv("FFGPU_DIAG_REGISTER_INPUT") ? NULL : ffgpu_host_alloc(in_floats * sizeof(float));
+    if (ext->pinned_input) { free(l0->data); l0->data = ext->pinned_input; }
     return net;
 }
 
@@ -304,6 +308,11 @@ void net_free(NET *net)
     ffcnn_ext *ext = ffcnn_ext_of(net);
     if (ext) {
         if (ext->dev) ffgpu_netdev_destroy(ext->dev);
+        if (ext->pinned_input) {                             /* goes back to the runtime, not to free() */
+            if (net->layer_list[0].data == ext->pinned_input) net->layer_list[0].data = NULL;
+            ffgpu_host_free(ext->pinned_input);
+            ext->pinned_input = NULL;
+        }
         free(ext->own_boxes);
         ext->magic = 0;
     }

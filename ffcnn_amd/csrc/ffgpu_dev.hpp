@@ -73,6 +73,7 @@ struct ExecParams {
     int s1, s2;               // box rescale ratio (ffcnn.c:267-273), applied by k_nms
     ffgpu_frame_dets *ring;   // record ring of the multi-GPU gather (ffgpu_exec_set_ring), or NULL
     int ring_slots, ring_stride;
+    int bbox_max;             // NET.bbox_max of this forward: the reference re-reads it on every net_forward (ffcnn.c:461-463)
 };
 int  ffgpu_launch_set_params(ExecParams *d_prm, const ExecParams &v, hipStream_t s);
 bool ffgpu_conv_supports_ind(const ConvDesc &d);    // the kernel ffgpu_launch_conv would pick reads ConvDesc::in_ind
@@ -101,7 +102,7 @@ int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand,
 // full (may be NULL): cap boxes per frame, ALL survivors in score order (the fixed-size record keeps the first FFGPU_MAX_DET)
 // bbox_max: the reference stops appending candidates at net->bbox_max in emission order (ffcnn.c:463); same here
 // scratch (cap_pow2 > FFGPU_NMS_LDS_CAP only): 12 bytes x cap_pow2 per frame of global memory instead of LDS
-int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, int bbox_max, BBOX *full, void *scratch,
+int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, BBOX *full, void *scratch,
                      ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, const int *ring_ctr, int N,
                      float thresh, int use_min, const ExecParams *prm, hipStream_t s);
 #define FFGPU_NMS_LDS_CAP 8192

@@ -58,6 +58,68 @@ extern "C" int ffgpu_set_device(int ordinal)
     return 0;
 }
 
+// -------------------------------------------------------------------------- host <-> device transfers
+// Rule (round 3): the GPU never reads or writes a page of the CALLER's heap.  A copy from / to pageable
+// memory makes the runtime map those pages for the device (hipHostRegister explicitly, a large hipMemcpy implicitly), and mapping
+// and unmapping malloc pages that glibc hands out again, trims and re-grows took the process down about once in ten to thirty
+// load / plan / run / free sequences ("Memory access fault by GPU ... on address <a heap address>", GPUTEST_r02's abort).  Every
+// transfer between caller memory and the device therefore goes through page-locked memory that the HIP runtime itself allocated
+// (hipHostMalloc) and this library owns: the input tensor of a NET, an executor's / node's staging buffers, or the process-wide
+// bounce buffer below.  Memory handed out by ffgpu_host_alloc is recognised and copied from directly (one DMA).
+namespace {
+struct PinnedRange { const char *p; size_t bytes; };
+std::mutex g_pin_mu;
+std::vector<PinnedRange> g_pinned;
+
+bool pinned_ours(const void *ptr, size_t bytes)
+{
+    const char *c = static_cast<const char *>(ptr);
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (const PinnedRange &r : g_pinned) if (c >= r.p && c + bytes <= r.p + r.bytes) return true;
+    return false;
+}
+
+constexpr size_t BOUNCE_BYTES = (size_t)16 << 20;
+std::mutex g_bounce_mu;
+char *g_bounce = nullptr;            // allocated on first use, kept for the life of the process (portable: every device may DMA from it)
+
+int bounce_ready()
+{
+    if (g_bounce) return 0;
+    FFGPU_CHECK(hipHostMalloc((void **)&g_bounce, BOUNCE_BYTES, hipHostMallocPortable));
+    return 0;
+}
+}
+
+// synchronous copies between caller memory and device memory, in chunks through the bounce buffer
+static int copy_h2d(void *d_dst, const void *h_src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    if (pinned_ours(h_src, bytes)) { FFGPU_CHECK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); return 0; }
+    std::lock_guard<std::mutex> lk(g_bounce_mu);
+    if (bounce_ready()) return -1;
+    for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
+        const size_t n = std::min(BOUNCE_BYTES, bytes - off);
+        memcpy(g_bounce, static_cast<const char *>(h_src) + off, n);
+        FFGPU_CHECK(hipMemcpy(static_cast<char *>(d_dst) + off, g_bounce, n, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+static int copy_d2h(void *h_dst, const void *d_src, size_t bytes)
+{
+    if (bytes == 0) return 0;
+    if (pinned_ours(h_dst, bytes)) { FFGPU_CHECK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost)); return 0; }
+    std::lock_guard<std::mutex> lk(g_bounce_mu);
+    if (bounce_ready()) return -1;
+    for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
+        const size_t n = std::min(BOUNCE_BYTES, bytes - off);
+        FFGPU_CHECK(hipMemcpy(g_bounce, static_cast<const char *>(d_src) + off, n, hipMemcpyDeviceToHost));
+        memcpy(static_cast<char *>(h_dst) + off, g_bounce, n);
+    }
+    return 0;
+}
+
 // --------------------------------------------------------------------------
 #define FFGPU_INTERNAL_CHILD 0x40000000   /* executor flag used only inside this file: a half of a split executor */
 
@@ -99,7 +161,7 @@ struct ffgpu_netdev {
     size_t weight_bytes = 0;
     int    device = 0;
     ffgpu_exec *exec1 = nullptr;
-    void  *pinned_input = nullptr;     // layer_list[0].data registered with the driver (net_forward's H2D copy is then a DMA, not a staged copy)
+    void  *diag_registered = nullptr;  // TEMPORARY: see FFGPU_DIAG_REGISTER_INPUT
 };
 
 struct ffgpu_exec {
@@ -126,6 +188,7 @@ struct ffgpu_exec {
     const float *last_frames = nullptr;   // input of the last forward (read_layer(-1))
     ffgpu_frame_dets *d_dets = nullptr;
     ffgpu_frame_dets *h_dets = nullptr, *h_dets_dev = nullptr;   // FFGPU_HOST_DETS: pinned mirror and its device address
+    float *h_stage = nullptr;          // ffgpu_exec_forward_host from caller memory: page-locked staging of one batch (on first use)
     ffgpu_frame_dets *ring = nullptr; int ring_slots = 0; int *d_ringctr = nullptr;   // ffgpu_exec_set_ring
     int ring_stride = 0;               // records per ring slot (the parent's batch for the halves of a split executor)
     static constexpr int MAXPART = 8;
@@ -627,7 +690,7 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
         return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->cand_cap,
                                  st.flag ? ex->d_ringctr : nullptr, s);          // forwards are counted whether or not a ring is attached
     case S_NMS:
-        return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->cand_cap, ex->bbox_max, ex->d_full, ex->d_nms_scratch,
+        return ffgpu_launch_nms(ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->cand_cap, ex->d_full, ex->d_nms_scratch,
                                 ex->d_dets, ex->h_dets_dev, ex->d_ringctr, ex->N, 0.5f, 1, ex->d_prm, s);
     }
     return -1;
@@ -685,7 +748,7 @@ static int push_params(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
     if (ex->child[0]) {
         const size_t part = (size_t)ex->child[0]->N * ex->in_c * ex->in_h * ex->in_w;
         for (int c = 0; c < ex->nchild; c++) {
-            ex->child[c]->s1 = ex->s1; ex->child[c]->s2 = ex->s2; ex->child[c]->last_stream = s;
+            ex->child[c]->s1 = ex->s1; ex->child[c]->s2 = ex->s2; ex->child[c]->bbox_max = ex->bbox_max; ex->child[c]->last_stream = s;
             if (push_params(ex->child[c], d_frames + c * part, s)) return -1;
         }
         return 0;
@@ -694,6 +757,7 @@ static int push_params(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
     ExecParams v;
     memset(&v, 0, sizeof v);
     v.frames = d_frames; v.s1 = ex->s1; v.s2 = ex->s2;
+    v.bbox_max = ex->bbox_max;
     v.ring = ex->ring; v.ring_slots = ex->ring_slots; v.ring_stride = ex->ring_stride ? ex->ring_stride : ex->N;
     if (ex->prm_valid && ex->prm_stream == s && memcmp(&v, &ex->prm_sent, sizeof v) == 0) return 0;
     if (ffgpu_launch_set_params(ex->d_prm, v, s)) return -1;
@@ -913,6 +977,7 @@ extern "C" void ffgpu_exec_destroy(ffgpu_exec *ex)
     (void)hipFree(ex->d_cand_key); (void)hipFree(ex->d_ncand); (void)hipFree(ex->d_dets);
     (void)hipFree(ex->d_full); (void)hipFree(ex->d_prm); (void)hipFree(ex->d_nms_scratch);
     if (ex->h_dets) (void)hipHostFree(ex->h_dets);
+    if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     (void)hipFree(ex->d_ringctr);
     if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
     if (ex->side_stream) (void)hipStreamDestroy(ex->side_stream);
@@ -1000,7 +1065,14 @@ extern "C" int ffgpu_exec_forward_host(ffgpu_exec *ex, const float *h_frames)
     if (!h_frames) { ffgpu_set_error("forward_host: NULL argument"); return -1; }
     if (ensure_input(ex)) return -1;
     const size_t bytes = sizeof(float) * (size_t)ex->N * ex->in_c * ex->in_h * ex->in_w;
-    FFGPU_CHECK(hipMemcpyAsync(ex->d_input, h_frames, bytes, hipMemcpyHostToDevice, ex->own_stream));
+    if (pinned_ours(h_frames, bytes)) {                          // (a NET's input tensor: one DMA, in stream order with the forward)
+        FFGPU_CHECK(hipMemcpyAsync(ex->d_input, h_frames, bytes, hipMemcpyHostToDevice, ex->own_stream));
+    } else {
+        // caller memory: through the executor's own page-locked staging buffer (allocated on the first such call)
+        if (!ex->h_stage) FFGPU_CHECK(hipHostMalloc((void **)&ex->h_stage, bytes, hipHostMallocDefault));
+        memcpy(ex->h_stage, h_frames, bytes);                    // (the previous forward_host of this executor ended with a stream sync)
+        FFGPU_CHECK(hipMemcpyAsync(ex->d_input, ex->h_stage, bytes, hipMemcpyHostToDevice, ex->own_stream));
+    }
     if (forward_on(ex, ex->d_input, ex->own_stream)) return -1;
     FFGPU_CHECK(hipStreamSynchronize(ex->own_stream));
     return 0;
@@ -1064,7 +1136,7 @@ extern "C" int ffgpu_exec_read_dets(ffgpu_exec *ex, ffgpu_frame_dets *host_out, 
     const int n = std::max(0, std::min(max_frames, ex->N));
     FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
     if (ex->h_dets) memcpy(host_out, ex->h_dets, sizeof(ffgpu_frame_dets) * (size_t)n);
-    else FFGPU_CHECK(hipMemcpy(host_out, ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)n, hipMemcpyDeviceToHost));
+    else { if (copy_d2h(host_out, ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)n)) return -1; }
     return n;
 }
 
@@ -1082,9 +1154,9 @@ extern "C" int ffgpu_exec_read_boxes(ffgpu_exec *ex, int frame, BBOX *host_out, 
     if (!ex || frame < 0 || frame >= ex->N || cap < 0 || (cap > 0 && !host_out)) { ffgpu_set_error("read_boxes: bad arguments"); return -1; }
     FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
     int nfull = 0;
-    FFGPU_CHECK(hipMemcpy(&nfull, &ex->d_dets[frame].nfull, sizeof(int), hipMemcpyDeviceToHost));
+    if (copy_d2h(&nfull, &ex->d_dets[frame].nfull, sizeof(int))) return -1;
     const int n = std::min(nfull, cap);
-    if (n > 0) FFGPU_CHECK(hipMemcpy(host_out, ex->d_full + (size_t)frame * ex->cand_cap, sizeof(BBOX) * (size_t)n, hipMemcpyDeviceToHost));
+    if (n > 0 && copy_d2h(host_out, ex->d_full + (size_t)frame * ex->cand_cap, sizeof(BBOX) * (size_t)n)) return -1;
     return nfull;
 }
 
@@ -1096,14 +1168,14 @@ extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float
     FFGPU_CHECK(hipStreamSynchronize(ex->last_stream));
     if (layer == -2) {                                            // candidates in reference emission order
         int cnt = 0;
-        FFGPU_CHECK(hipMemcpy(&cnt, &ex->d_dets[frame].ncand, sizeof(int), hipMemcpyDeviceToHost));    // (k_nms has reset d_ncand)
+        if (copy_d2h(&cnt, &ex->d_dets[frame].ncand, sizeof(int))) return -1;    // (k_nms has reset d_ncand)
         cnt = std::min(cnt, ex->cand_cap);
         if ((size_t)cnt * 6 > cap_floats) { ffgpu_set_error("read_layer: buffer too small"); return -1; }
         std::vector<BBOX> b(cnt);
         std::vector<int> k(cnt), idx(cnt);
         if (cnt) {
-            FFGPU_CHECK(hipMemcpy(b.data(), ex->d_cand + (size_t)frame * ex->cand_cap, sizeof(BBOX) * cnt, hipMemcpyDeviceToHost));
-            FFGPU_CHECK(hipMemcpy(k.data(), ex->d_cand_key + (size_t)frame * ex->cand_cap, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+            if (copy_d2h(b.data(), ex->d_cand + (size_t)frame * ex->cand_cap, sizeof(BBOX) * cnt)) return -1;
+            if (copy_d2h(k.data(), ex->d_cand_key + (size_t)frame * ex->cand_cap, sizeof(int) * cnt)) return -1;
         }
         for (int i = 0; i < cnt; i++) idx[i] = i;
         std::sort(idx.begin(), idx.end(), [&](int a, int c) { return k[a] < k[c]; });
@@ -1114,7 +1186,7 @@ extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float
         const size_t fl = (size_t)ex->in_c * ex->in_h * ex->in_w;
         if (!ex->last_frames) { ffgpu_set_error("read_layer: no forward has run yet"); return -1; }
         if (fl > cap_floats) { ffgpu_set_error("read_layer: buffer too small"); return -1; }
-        FFGPU_CHECK(hipMemcpy(host_out, ex->last_frames + (size_t)frame * fl, fl * sizeof(float), hipMemcpyDeviceToHost));
+        if (copy_d2h(host_out, ex->last_frames + (size_t)frame * fl, fl * sizeof(float))) return -1;
         return (int)fl;
     }
     if (!(ex->flags & FFGPU_KEEP_ALL)) { ffgpu_set_error("read_layer needs an FFGPU_KEEP_ALL executor"); return -1; }
@@ -1126,8 +1198,17 @@ extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float
     const size_t plane = (size_t)o.w * o.h;
     if (plane * o.c > cap_floats) { ffgpu_set_error("read_layer: buffer too small"); return -1; }
     const float *src = tensor_ptr(ex, ex->canon[layer]) + (size_t)frame * plane;
-    FFGPU_CHECK(hipMemcpy2D(host_out, plane * sizeof(float), src, plane * ex->N * sizeof(float),
-                            plane * sizeof(float), o.c, hipMemcpyDeviceToHost));
+    {   // the frame's planes (one per channel, N planes apart in CNHW) gathered into the bounce buffer, then into caller memory
+        const size_t row = plane * sizeof(float), per = std::max<size_t>(1, BOUNCE_BYTES / row);
+        if (row > BOUNCE_BYTES) { ffgpu_set_error("read_layer: a plane of %zu bytes exceeds the staging buffer", row); return -1; }
+        std::lock_guard<std::mutex> lk(g_bounce_mu);
+        if (bounce_ready()) return -1;
+        for (size_t c0 = 0; c0 < (size_t)o.c; c0 += per) {
+            const size_t nc = std::min(per, (size_t)o.c - c0);
+            FFGPU_CHECK(hipMemcpy2D(g_bounce, row, src + c0 * plane * ex->N, row * ex->N, row, nc, hipMemcpyDeviceToHost));
+            memcpy(host_out + c0 * plane, g_bounce, nc * row);
+        }
+    }
     return (int)(plane * o.c);
 }
 
@@ -1208,7 +1289,7 @@ static ffgpu_netdev *netdev_create_on(NET *net, int device, bool upload)
     else if (hipGetDevice(&dev->device) != hipSuccess) dev->device = 0;
     dev->weight_bytes = sizeof(float) * (size_t)std::max(net->weight_size, 1);
     if (hipMalloc(&dev->d_weights, dev->weight_bytes) != hipSuccess ||
-        (upload ? hipMemcpy(dev->d_weights, net->weight_buf, sizeof(float) * (size_t)net->weight_size, hipMemcpyHostToDevice)
+        (upload ? (copy_h2d(dev->d_weights, net->weight_buf, sizeof(float) * (size_t)net->weight_size) ? hipErrorUnknown : hipSuccess)
                 : hipMemset(dev->d_weights, 0, dev->weight_bytes)) != hipSuccess ||
         hipStreamSynchronize(nullptr) != hipSuccess) {                // (the memset is asynchronous on the NULL stream: a broadcast on
                                                                       //  another stream must not be overtaken by it)
@@ -1222,12 +1303,31 @@ static ffgpu_netdev *netdev_create_on(NET *net, int device, bool upload)
 
 extern "C" void *ffgpu_netdev_create(NET *net) { return netdev_create_on(net, -1, true); }
 
+extern "C" float *ffgpu_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    memset(p, 0, bytes);
+    { std::lock_guard<std::mutex> lk(g_pin_mu); g_pinned.push_back({ (const char *)p, bytes }); }
+    return (float *)p;
+}
+
+extern "C" void ffgpu_host_free(float *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t i = 0; i < g_pinned.size(); i++) if (g_pinned[i].p == (const char *)p) { g_pinned.erase(g_pinned.begin() + i); break; }
+    }
+    (void)hipHostFree(p);
+}
+
 extern "C" void ffgpu_netdev_destroy(void *p)
 {
     ffgpu_netdev *dev = (ffgpu_netdev *)p;
     if (!dev) return;
     if (dev->exec1) { ffgpu_exec_destroy(dev->exec1); dev->exec1 = nullptr; }
-    if (dev->pinned_input) { (void)hipHostUnregister(dev->pinned_input); dev->pinned_input = nullptr; }    // (net_free frees it right after)
+    if (dev->diag_registered) { (void)hipHostUnregister(dev->diag_registered); dev->diag_registered = nullptr; }
     // executors the caller still holds outlive the net as orphans: their steps point into d_weights and the layer table,
     // so they wait for their streams here and from now on refuse to run (alive()); ffgpu_exec_destroy still frees them
     std::vector<ffgpu_exec *> left;
@@ -1250,12 +1350,14 @@ extern "C" int ffgpu_netdev_forward1(NET *net, void *p, int profile)
     ffgpu_netdev *dev = (ffgpu_netdev *)p;
     if (!dev->exec1) {
         // one frame at a time is latency: the records come back through the pinned host mirror (no device-to-host copy), and the
-        // input tensor the application fills is page-locked so that its upload is one DMA (best effort: a failure only costs time)
+        // input tensor the application fills is page-locked memory of the runtime since net_load (ffgpu_host_alloc): one DMA up
         dev->exec1 = ffgpu_exec_create(net, 1, FFGPU_HOST_DETS);
         if (!dev->exec1) return -1;
-        const LAYER *l0 = net->layer_list;
-        if (l0->data && hipHostRegister(l0->data, sizeof(float) * (size_t)l0->c * l0->h * l0->w, hipHostRegisterDefault) == hipSuccess) dev->pinned_input = l0->data;
-        else (void)hipGetLastError();
+        if (getenv("FFGPU_DIAG_REGISTER_INPUT")) {               // TEMPORARY (round-3 diagnosis of GPUTEST_r02's abort): round 2's behaviour
+            const LAYER *l0 = net->layer_list;
+            if (hipHostRegister(l0->data, sizeof(float) * (size_t)l0->c * l0->h * l0->w, hipHostRegisterDefault) == hipSuccess) dev->diag_registered = l0->data;
+            else (void)hipGetLastError();
+        }
     }
     ffgpu_exec *ex = dev->exec1;
     ex->s1 = net->s1 ? net->s1 : 1;
@@ -1263,7 +1365,7 @@ extern "C" int ffgpu_netdev_forward1(NET *net, void *p, int profile)
     ex->bbox_max = std::max(net->bbox_max, 1);
     if (profile) {
         if (ensure_input(ex)) return -1;
-        FFGPU_CHECK(hipMemcpy(ex->d_input, net->layer_list[0].data, sizeof(float) * (size_t)ex->in_c * ex->in_h * ex->in_w, hipMemcpyHostToDevice));
+        if (copy_h2d(ex->d_input, net->layer_list[0].data, sizeof(float) * (size_t)ex->in_c * ex->in_h * ex->in_w)) return -1;
         float us[LAYER_TYPE_TOTOAL];
         if (ffgpu_exec_profile(ex, ex->d_input, us)) return -1;
         for (int k = 0; k < LAYER_TYPE_TOTOAL; k++) { dev->us_acc[k] += us[k]; net->timeused[k] = (int)(dev->us_acc[k] / 1000.0 + 0.5); }
@@ -1471,9 +1573,8 @@ extern "C" void groupconv(float *in, float *filt, float *out,
         sc.dev = cur;
     }
     int rc = grow(&sc.in, &sc.in_n, n_in) || grow(&sc.filt, &sc.filt_n, n_f) || grow(&sc.out, &sc.out_n, n_out);
-    if (!rc) rc = hipMemcpy(sc.in, in, n_in * sizeof(float), hipMemcpyHostToDevice) != hipSuccess
-               || hipMemcpy(sc.filt, filt, n_f * sizeof(float), hipMemcpyHostToDevice) != hipSuccess;
+    if (!rc) rc = copy_h2d(sc.in, in, n_in * sizeof(float)) || copy_h2d(sc.filt, filt, n_f * sizeof(float));   // (staged: DESIGN.md section 10)
     if (!rc) rc = ffgpu_groupconv_dev(sc.in, sc.filt, sc.out, 1, iw, ih, ic, ig, ipad, istride, fs, fn, ow, oh, oc, act, flags, FFGPU_K_AUTO, nullptr);
-    if (!rc) rc = hipMemcpy(out, sc.out, n_out * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess;   // syncs the null stream
+    if (!rc) rc = hipStreamSynchronize(nullptr) != hipSuccess || copy_d2h(out, sc.out, n_out * sizeof(float));
     if (rc) fprintf(stderr, "ffcnn groupconv: device path failed: %s\n", g_err[0] ? g_err : hipGetErrorString(hipGetLastError()));
 }

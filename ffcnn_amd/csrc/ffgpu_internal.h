@@ -21,6 +21,7 @@ typedef struct {
     void    *dev;              /* ffgpu_netdev* (device weights + executors)    */
     BBOX    *own_boxes;        /* bbox_list storage (NOT aliased onto the input)*/
     int      box_cap;          /* boxes own_boxes has room for (= bbox_max at load) */
+    float   *pinned_input;     /* layer_list[0].data when it is page-locked memory of the HIP runtime (ffgpu_host_alloc) */
 } ffcnn_ext;
 
 static inline ffcnn_ext *ffcnn_ext_of(NET *net)
@@ -35,6 +36,10 @@ void  ffgpu_netdev_destroy(void *dev);
 int   ffgpu_netdev_forward1(NET *net, void *dev, int profile); /* one frame from layer_list[0].data -> bbox_list;  */
                                                   /* profile: per-kind device time added to net->timeused  */
 int   ffgpu_netdev_profile_us(void *dev, double us_by_kind[LAYER_TYPE_TOTOAL]);   /* the same, in microseconds */
+/* page-locked host memory owned by the HIP runtime (hipHostMalloc / hipHostFree), zero-filled; NULL on failure.  The input
+ * tensor lives there: its upload is one DMA and no heap page is ever registered / unregistered */
+float *ffgpu_host_alloc(size_t bytes);
+void   ffgpu_host_free(float *p);
 void  ffgpu_set_error(const char *fmt, ...);
 
 #ifdef __cplusplus

@@ -364,7 +364,7 @@ __global__ void k_yolo(YoloHead hd, int N, int netw, int neth, BBOX *cand, int *
 // full (may be NULL): ALL survivors of the frame in score order (cap slots per frame); the fixed-size record holds the first
 // FFGPU_MAX_DET of them and their total number in `nfull`
 template <bool GLB>
-__global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, int cap_p2, int bbox_max,
+__global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, int cap_p2,
                                              BBOX *full, unsigned char *scratch,
                                              ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host,
                                              const int *ring_ctr, float thresh, int use_min, const ExecParams *prm)
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) k_nms(const BBOX *cand, const int *cand_k
     int   *s_idx = reinterpret_cast<int *>(wb + (size_t)8 * cap_p2);
     unsigned char *s_alive = wb + (size_t)12 * cap_p2;
     const int n = blockIdx.x, tid = threadIdx.x;
-    const int s1 = prm->s1, s2 = prm->s2;
+    const int s1 = prm->s1, s2 = prm->s2, bbox_max = prm->bbox_max;   // (in the parameter block: a graph replays with this forward's values)
     ffgpu_frame_dets *const ring = prm->ring;                   // (the ring travels in the parameter block too: attaching or
     const int ring_slots = prm->ring_slots, ring_stride = prm->ring_stride;   //  restarting it does not invalidate the graph)
     const int total = ncand[n];
@@ -607,7 +607,7 @@ int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand,
     return 0;
 }
 
-int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, int bbox_max, BBOX *full, void *scratch,
+int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, BBOX *full, void *scratch,
                      ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, const int *ring_ctr, int N,
                      float thresh, int use_min, const ExecParams *prm, hipStream_t s)
 {
@@ -615,12 +615,12 @@ int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap,
     while (p2 < cap) p2 <<= 1;
     if (p2 > FFGPU_NMS_LDS_CAP) {
         if (!scratch) { ffgpu_set_error("nms: %d candidate slots per frame need the global scratch buffer", cap); return -1; }
-        hipLaunchKernelGGL(k_nms<true>, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, cap, p2, bbox_max, full, (unsigned char *)scratch,
+        hipLaunchKernelGGL(k_nms<true>, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, cap, p2, full, (unsigned char *)scratch,
                            dets, dets_host, ring_ctr, thresh, use_min, prm);
     } else {
         const size_t lds = (size_t)13 * p2;
         if (lds_allow((const void *)k_nms<false>, lds > 64 * 1024 ? (size_t)13 * FFGPU_NMS_LDS_CAP : lds, "nms")) return -1;
-        hipLaunchKernelGGL(k_nms<false>, dim3(N), dim3(256), lds, s, cand, cand_key, ncand, cap, p2, bbox_max, full, nullptr,
+        hipLaunchKernelGGL(k_nms<false>, dim3(N), dim3(256), lds, s, cand, cand_key, ncand, cap, p2, full, nullptr,
                            dets, dets_host, ring_ctr, thresh, use_min, prm);
     }
     LAUNCH_OK("nms");
@@ -643,8 +643,8 @@ int ffgpu_launch_clear(int *ncand, int N, int *ring_ctr, hipStream_t s)
 
 // ---- compact form of the detection records for the multi-GPU gather: a step's `batch` fixed-size records (3088 bytes
 // each, almost all of it unused box slots) become
-//     int total, over, batch, cap | { int count, ncand, overflow, first } x batch | BBOX box[cap]
-// with each frame's boxes packed behind each other (frame order; `first` = index of its first box).  A step whose frames
+//     int total, over, batch, cap | { int count, ncand, overflow, nfull } x batch | BBOX box[cap]
+// with each frame's boxes packed behind each other (frame order: a frame's first box sits at the sum of the counts before it).  A step whose frames
 // hold more than `cap` boxes together keeps the first cap of them and says so (`over`, and `overflow |= 2` on the frames
 // that lost boxes).  One workgroup per step; 25 KB instead of 198 KB per step at batch 64, cap 1024.
 __global__ void __launch_bounds__(256) k_pack_records(const ffgpu_frame_dets *recs, long slot_stride_recs, int batch, int cap, unsigned char *out, long out_stride)
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(256) k_pack_records(const ffgpu_frame_dets *re
     __syncthreads();
     for (int n = threadIdx.x; n < batch; n += blockDim.x) {
         const int first = s_first[n], cnt = r[n].count, kept = max(0, min(cnt, cap - first));
-        fr[4 * n] = kept; fr[4 * n + 1] = r[n].ncand; fr[4 * n + 2] = r[n].overflow | (kept < cnt ? 2 : 0); fr[4 * n + 3] = min(first, cap);
+        fr[4 * n] = kept; fr[4 * n + 1] = r[n].ncand; fr[4 * n + 2] = r[n].overflow | (kept < cnt ? 2 : 0); fr[4 * n + 3] = r[n].nfull;
     }
     // boxes: 6 floats each, copied as 32-bit words by the whole workgroup
     for (int n = 0; n < batch; n++) {

@@ -84,8 +84,10 @@ def unpack_records(block, dets_dtype):
     fr = b[16:16 + 16 * batch].view(np.int32).reshape(batch, 4)
     box = b[16 + 16 * batch:16 + 16 * batch + box_dtype.itemsize * cap].view(box_dtype)
     out = np.zeros(batch, dets_dtype)
+    first = 0                                                   # boxes lie behind each other in frame order
     for n in range(batch):
-        kept, ncand, ovf, first = (int(v) for v in fr[n])
-        out[n]["count"], out[n]["ncand"], out[n]["overflow"] = kept, ncand, ovf
+        kept, ncand, ovf, nfull = (int(v) for v in fr[n])
+        out[n]["count"], out[n]["ncand"], out[n]["overflow"], out[n]["nfull"] = kept, ncand, ovf, nfull
         out[n]["box"][:kept] = box[first:first + kept]
+        first += kept
     return out

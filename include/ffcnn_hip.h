@@ -188,7 +188,8 @@ int         ffgpu_node_forward(ffgpu_node *node, ffgpu_frame_dets *host_out);
 int         ffgpu_node_forward_host(ffgpu_node *node, const float *h_frames, ffgpu_frame_dets *host_out);
 /* Pipelined form: submit enqueues the next step on every device (h_frames may be NULL: the slot's input buffers are used as
  * they are) plus its gather and returns the step's ticket (>= 0) without waiting; wait(ticket) blocks until that step's
- * records are on the host and copies them.  At most `depth` tickets may be outstanding. */
+ * records are on the host and copies them.  At most `depth` tickets may be outstanding.  h_frames is copied into the slot's
+ * page-locked staging buffer before submit returns: the caller's buffer is free again at once. */
 long        ffgpu_node_submit(ffgpu_node *node, const float *h_frames);
 int         ffgpu_node_wait(ffgpu_node *node, long ticket, ffgpu_frame_dets *host_out);
 
@@ -244,8 +245,8 @@ float ffgpu_dwpw_dev(const float *d_in, const float *d_wd, const float *d_wp, fl
 /* ---- compact records for the multi-GPU gather ("fixed-size detection records to rank 0"): the
  * `batch` records of each of `nslots` steps (slot s starts at record s * slot_stride_records of d_records, e.g. a ring
  * set with ffgpu_exec_set_ring) are packed into nslots blocks of ffgpu_packed_records_bytes(batch, cap) bytes:
- *     int total, over, batch, cap | { int count, ncand, overflow, first } x batch | BBOX box[cap]
- * boxes of the frames behind each other in frame order.  A step with more than `cap` boxes keeps the first `cap`
+ *     int total, over, batch, cap | { int count, ncand, overflow, nfull } x batch | BBOX box[cap]
+ * boxes of the frames behind each other in frame order (a frame's first box sits at the sum of the counts before it).  A step with more than `cap` boxes keeps the first `cap`
  * (over = 1, overflow |= 2 on the frames that lost boxes).  ffcnn_amd/dist.py unpacks them on the host. */
 size_t ffgpu_packed_records_bytes(int batch, int cap);
 int    ffgpu_pack_records(const void *d_records, int nslots, long slot_stride_records, int batch, int cap, void *d_out, void *stream);

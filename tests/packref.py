@@ -17,7 +17,7 @@ def pack_records(recs, cap):
     for n in range(batch):
         cnt = int(recs[n]["count"])
         kept = max(0, min(cnt, cap - first))
-        fr[n] = (kept, recs[n]["ncand"], int(recs[n]["overflow"]) | (2 if kept < cnt else 0), min(first, cap))
+        fr[n] = (kept, recs[n]["ncand"], int(recs[n]["overflow"]) | (2 if kept < cnt else 0), int(recs[n]["nfull"]))
         box[min(first, cap):min(first, cap) + kept] = recs[n]["box"][:kept]
         first += cnt
     hdr[:] = (min(first, cap), int(first > cap), batch, cap)

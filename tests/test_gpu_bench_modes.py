@@ -10,6 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--steps", "8", "--warmup", "4", "--no-cpu-baseline", "--no-kernel-roofline", "--no-extras"]
+NO_NODE = ["--no-node-line"]
 
 
 def run(cmd, port=None):
@@ -35,19 +36,38 @@ def check_line(d, scaling, frames):
 
 @pytest.mark.gpu
 def test_bench_default_step():
-    check_line(run([sys.executable, "bench.py"] + COMMON), "weak", 64)
+    d = run([sys.executable, "bench.py"] + COMMON)
+    check_line(d, "weak", 64)
+    assert d["config"]["untimed_forwards_before_t0"] > 0
+    # beside it: the same job through the C node API (a child `bench.py --node`), same metric, boxes checked there as well
+    c = d["c_node_api"]
+    assert "error" not in c, c
+    assert c["unit"] == "frames/s" and c["value"] > 0 and c["n_gpus"] == 1 and "C node API" in c["host"]
+    assert c["config"]["boxes_match_reference_golden_frame0"] is True
+
+
+@pytest.mark.gpu
+def test_bench_node_mode():
+    """bench.py --node: one process, ffgpu_node_create / submit / wait (the C host path of north_star), same JSON contract"""
+    d = run([sys.executable, "bench.py", "--node", "--steps", "8", "--warmup", "4", "--depth", "4"])
+    assert d["unit"] == "frames/s" and d["value"] > 0 and d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 4
+    assert d["scaling"] == "weak" and d["dtype"] == "f32" and d["config"]["global_batch"] == 64
+    assert d["config"]["boxes_match_reference_golden_frame0"] is True
+    assert abs(d["value"] - 64 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-3
+    d = run([sys.executable, "bench.py", "--node", "--steps", "4", "--warmup", "2", "--global-batch", "256", "--depth", "2"])
+    assert d["scaling"] == "strong" and d["config"]["global_batch"] == 256 and d["config"]["boxes_match_reference_golden_frame0"] is True
 
 
 @pytest.mark.gpu
 def test_bench_gather_step_under_torchrun():
     d = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-             "--master-port", "29541", "bench.py", "--gpus", "1", "--force-gather"] + COMMON)
+             "--master-port", "29541", "bench.py", "--gpus", "1", "--force-gather"] + COMMON + NO_NODE)
     check_line(d, "weak", 64)
     assert "RCCL gather" in d["config"]["gather"]
 
 
 @pytest.mark.gpu
 def test_bench_strong_scaling_job():
-    d = run([sys.executable, "bench.py", "--force-gather", "--global-batch", "256"] + COMMON, port=29543)
+    d = run([sys.executable, "bench.py", "--force-gather", "--global-batch", "256"] + COMMON + NO_NODE, port=29543)
     check_line(d, "strong", 256)
     assert d["config"]["frames_per_gpu"] == 256

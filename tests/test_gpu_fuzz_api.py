@@ -108,6 +108,7 @@ def test_random_api_walk(pool, seed):
                 e["ex"].close()
 
 
+@pytest.mark.isolated
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FFCNN_FUZZ_SEED0", "0")), int(os.environ.get("FFCNN_FUZZ_SEED0", "0")) + int(os.environ.get("FFCNN_FUZZ_WALKS", "4"))))
 def test_random_node_walk(pool, seed):
     """the C node path (ffgpu_node_*: shards, per-rank executors, gather offsets, pipelined slots) on one device through the
@@ -150,6 +151,7 @@ def test_random_node_walk(pool, seed):
             check(nd.wait(t), pk, sc, "drain wait(%d)" % t)
 
 
+@pytest.mark.isolated
 @pytest.mark.parametrize("seed", range(int(os.environ.get("FFCNN_FUZZ_SEED0", "0")), int(os.environ.get("FFCNN_FUZZ_SEED0", "0")) + int(os.environ.get("FFCNN_FUZZ_WALKS", "4"))))
 def test_random_lifecycle_walk(pool, test_image, seed):
     """object lifetimes: several NETs (native geometry and others) and their executors created, used through both API levels
@@ -210,6 +212,7 @@ def test_random_lifecycle_walk(pool, test_image, seed):
             e["n"].close()
 
 
+@pytest.mark.isolated
 def test_no_device_or_host_memory_leak(pool):
     """200 x (net_load, two executors, forwards through both API levels, destroy everything): the device's free memory and the
     process's resident set come back to where they were (a production host reloads models and re-plans executors for years)"""

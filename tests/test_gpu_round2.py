@@ -392,9 +392,9 @@ def test_profile_fills_timeused(F, test_image, monkeypatch, capfd):
 
 
 # ------------------------------------------------------------------ C-ABI multi-GPU node (one process)
-def test_node_one_gpu_over_rccl_equals_executor(F, net, eight):
-    """ffgpu_node_* with ndev = 1 through the real RCCL path (communicator, broadcast, gather are set up and degenerate):
-    byte-identical records to a plain executor of the same batch"""
+def test_node_one_gpu_equals_executor(F, net, eight):
+    """ffgpu_node_* with ndev = 1 (direct mode: no exchange exists, RCCL is not even loaded -- the N > 1 RCCL branch has its own
+    device-count-gated tests in test_gpu_node_rccl.py): byte-identical records to a plain executor of the same batch"""
     fr, runs = eight
     with net.executor(8, F.FFGPU.CONCURRENT) as ex:
         ex.set_scale(640, 320)
@@ -428,6 +428,30 @@ def test_node_multi_rank_loopback(F, net, eight, ranks, total):
                 boxes_match(dets[f]["box"][:dets[f]["count"]], runs[f]["boxes"], "rank layout %d/%d frame %d" % (ranks, total, f))
     with pytest.raises(RuntimeError, match="used twice"):
         F.Node(net, 2, 8, devices=[0, 0])                              # RCCL wants one rank per device
+
+
+def test_node_packed_gather_equals_executor_bytes(F, net, eight, monkeypatch):
+    """what ffgpu_node_wait hands over after pack -> gather -> unpack is byte-identical to the executors' own fixed-size records;
+    and a shard with more boxes than its packed block holds (FFGPU_NODE_PACK_BOXES=1: one box per frame on average, test.bmp alone
+    has three) is fetched again in full -- nothing is lost"""
+    fr, runs = eight
+    with net.executor(4, 0) as ex:                                 # (the plan depends on the batch: compare with the shards' own plan)
+        ex.set_scale(640, 320)
+        halves = []
+        for h in range(2):
+            ex.forward_host(fr[4 * h:4 * h + 4])
+            halves.append(ex.read_dets().copy())
+        want = np.concatenate(halves)
+    assert int(want["count"].sum()) > 8                            # (so that the 1-box-per-frame blocks do overflow)
+    for boxes in (None, "1"):
+        if boxes:
+            monkeypatch.setenv("FFGPU_NODE_PACK_BOXES", boxes)
+        with F.Node(net, 2, 8, node_flags=F.Node.LOOPBACK) as nd:
+            nd.set_scale(640, 320)
+            for _ in range(2):
+                got = nd.forward_host(fr)
+                assert got.tobytes() == want.tobytes(), "FFGPU_NODE_PACK_BOXES=%s" % boxes
+    monkeypatch.delenv("FFGPU_NODE_PACK_BOXES")
 
 
 def test_node_pipelined_steps(F, net, eight):
