@@ -232,7 +232,7 @@ def node_line(args, ngpus):
            if not (k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "GROUP_WORLD_SIZE",
                          "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") or k.startswith("TORCHELASTIC") or k.startswith("TORCH_NCCL"))}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--node", "--gpus", str(ngpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--depth", str(max(1, min(args.streams, 8)))]
+           "--depth", "8"]                                      # (a host that waits for every step's records needs a deeper pipeline than the enqueue-only loop above)
     if args.global_batch > 0:
         cmd += ["--global-batch", str(args.global_batch)]
     try:
@@ -296,14 +296,9 @@ def run_node(args):
         torch.cuda.synchronize(d)
     recs = np.zeros(G, capi.DETS_DTYPE)
 
-    def run(nsteps):
-        inflight = []
-        for _ in range(nsteps):
-            if len(inflight) == D:
-                nd.wait_into(inflight.pop(0), recs)
-            inflight.append(nd.submit())
-        for t in inflight:
-            nd.wait_into(t, recs)
+    def run(nsteps):                                            # the pipelined loop itself runs in C (ffgpu_node_run), as a C host's would
+        if nsteps > 0:
+            nd.run(nsteps, recs)
 
     pre = max(D, 128 // D * D)                                  # the device's sustained clock state (see main(): ~40 ms of forwards)
     run(pre)
@@ -327,7 +322,7 @@ def run_node(args):
            "value": round(G * args.steps / dt, 1), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "host": "C node API: one process, one host thread, ffgpu_node_submit / ffgpu_node_wait over include/ffcnn_hip.h",
+           "host": "C node API: one process, one host thread, ffgpu_node_run (= ffgpu_node_submit / ffgpu_node_wait, depth steps in flight) over include/ffcnn_hip.h",
            "config": {"workload": "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[%d])" % (4 if strong else 3),
                       "frames_per_gpu": G // N, "global_batch": G, "parallelism": "dp%d" % N, "steps_in_flight": D,
                       "exchange": "none (one device: the NMS kernel writes the records into pinned host memory)" if N == 1 else
@@ -368,7 +363,7 @@ def main():
     ap.add_argument("--node", action="store_true",
                     help="the C host path: ONE process drives all --gpus devices through ffgpu_node_create / submit / wait (RCCL broadcast of "
                          "the weights, packed gather of the records); not under torchrun")
-    ap.add_argument("--depth", type=int, default=4, help="--node: steps in flight (FFGPU_NODE_DEPTH; one executor per slot and device)")
+    ap.add_argument("--depth", type=int, default=8, help="--node: steps in flight (FFGPU_NODE_DEPTH; one executor per slot and device)")
     ap.add_argument("--no-node-line", action="store_true", help="skip the extra c_node_api measurement (a child `bench.py --node` run by rank 0 after the timed job)")
     args = ap.parse_args()
     if args.node:
@@ -411,7 +406,11 @@ def main():
     if strong:
         MS = args.merge_steps if args.merge_steps > 0 else max(1, 128 // B)
     Bx = MS * B                                                 # frames per launch
-    stream = torch.cuda.Stream()
+    # chain streams are PRIORITY streams: the runtime keeps a pool of (at most four) hardware queues per priority level, so the four
+    # chains get queues of their own whatever other streams the process holds (torch's, RCCL's) -- at the default priority which chains
+    # end up behind each other on one hardware queue depends on how many streams were created before them
+    prio = int(os.environ.get("FFCNN_BENCH_STREAM_PRIORITY", "-1"))
+    stream = torch.cuda.Stream(priority=prio)
     roof = roof_pw = None
     net = capi.Net()
     # weights: rank 0's folded filter rows -> every GPU over RCCL (one-off, outside the timed region)
@@ -450,7 +449,7 @@ def main():
     if S >= 3:
         flags |= capi.FFGPU.CONCURRENT      # plan for throughput: several chains fill the device together
     exs = [net.executor(Bx, flags) for _ in range(S)]
-    streams = [stream] + [torch.cuda.Stream() for _ in range(S - 1)]
+    streams = [stream] + [torch.cuda.Stream(priority=prio) for _ in range(S - 1)]
     ex = exs[0]
     model_bytes, model_flops = ex.work_model()
 

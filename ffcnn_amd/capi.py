@@ -66,7 +66,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_dwpw_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records",
            "ffgpu_shard_range", "ffgpu_node_create", "ffgpu_node_destroy", "ffgpu_node_ndev", "ffgpu_node_shard", "ffgpu_node_set_scale",
            "ffgpu_node_input_dev", "ffgpu_node_input_slot_dev", "ffgpu_node_depth", "ffgpu_node_forward", "ffgpu_node_forward_host",
-           "ffgpu_node_submit", "ffgpu_node_wait"]
+           "ffgpu_node_submit", "ffgpu_node_wait", "ffgpu_node_run"]
 # include/ffcnn_hip_diag.h (libffcnn_hip_diag.so: lab equipment, its own library)
 DIAG_EXPORTS = ["ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_pipe_probe2"]
 
@@ -163,6 +163,7 @@ def lib():
     L.ffgpu_node_submit.restype = C.c_long
     L.ffgpu_node_submit.argtypes = [vp, f32p]
     L.ffgpu_node_wait.argtypes = [vp, C.c_long, vp]
+    L.ffgpu_node_run.argtypes = [vp, C.c_long, vp]
     L.ffgpu_node_forward.argtypes = [vp, vp]
     L.ffgpu_node_forward_host.argtypes = [vp, f32p, vp]
     _lib = L
@@ -478,6 +479,14 @@ class Node:
         assert out.dtype == DETS_DTYPE and len(out) == self.total and out.flags["C_CONTIGUOUS"]
         _check(lib().ffgpu_node_wait(self.h, ticket, out.ctypes.data), "ffgpu_node_wait")
         self._held.pop(ticket, None)
+        return out
+
+    def run(self, steps, out=None):
+        """ffgpu_node_run: `steps` pipelined steps from the slots' input buffers (the loop runs in C); records of the last step"""
+        if out is None:
+            out = np.zeros(self.total, DETS_DTYPE)
+        assert out.dtype == DETS_DTYPE and len(out) == self.total and out.flags["C_CONTIGUOUS"]
+        _check(lib().ffgpu_node_run(self.h, steps, out.ctypes.data), "ffgpu_node_run")
         return out
 
     def input_slot_dev(self, rank, slot):

@@ -297,7 +297,7 @@ NET *net_load(char *cfg_path, char *weights_path, int inputw, int inputh)
     if (!ext->dev) { net_free(net); return NULL; }          /* no device, no net: error text already set */
     /* the tensor the application fills (net_input, or its own writes) moves into page-locked memory of the HIP runtime: net_forward
      * uploads it with one DMA.  Best effort -- a failure leaves the calloc'd tensor in place and only costs time. */
-    ext->pinned_input = getenv("FFGPU_DIAG_REGISTER_INPUT") ? NULL : ffgpu_host_alloc(in_floats * sizeof(float));
+    ext->pinned_input = ffgpu_host_alloc(in_floats * sizeof(float));
     if (ext->pinned_input) { free(l0->data); l0->data = ext->pinned_input; }
     return net;
 }

@@ -68,11 +68,8 @@ int main(int argc, char **argv)
         if (ffgpu_node_forward_host(node, frames, dets)) { fprintf(stderr, "forward failed: %s\n", ffgpu_last_error()); return 1; }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    long ticket[8];
-    for (int i = 0; i < steps + depth; i++) {                        /* `depth` steps in flight: collect step i - depth, submit step i */
-        if (i >= depth && ffgpu_node_wait(node, ticket[i % depth], dets)) { fprintf(stderr, "wait failed: %s\n", ffgpu_last_error()); return 1; }
-        if (i < steps && (ticket[i % depth] = ffgpu_node_submit(node, NULL)) < 0) { fprintf(stderr, "submit failed: %s\n", ffgpu_last_error()); return 1; }
-    }
+    /* `depth` steps in flight: collect step i - depth, submit step i (ffgpu_node_submit / ffgpu_node_wait in a loop, as one call) */
+    if (ffgpu_node_run(node, steps, dets)) { fprintf(stderr, "ffgpu_node_run failed: %s\n", ffgpu_last_error()); return 1; }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     const double dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     for (int i = 0; i < dets[0].count; i++) {

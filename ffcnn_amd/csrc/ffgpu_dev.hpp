@@ -54,7 +54,7 @@ size_t ffgpu_irb_pack_floats(const IrbDesc &d);
 int    ffgpu_irb_pack(const IrbDesc &d, float *pk, hipStream_t s);
 int    ffgpu_launch_irb(const IrbDesc &d, hipStream_t s);
 bool   ffgpu_front_ok(const ConvDesc &c, const IrbDesc &d);      // first layer (3x3 s2, 3 -> 8) + thin block as one streaming kernel
-int    ffgpu_launch_front(const ConvDesc &c, const IrbDesc &d, hipStream_t s);
+int    ffgpu_launch_front(const ConvDesc &c, const IrbDesc &d, hipStream_t s, bool u8 = false);
 
 // depthwise K x K (stride 1, same padding) + pointwise 1 x 1 as one launch (ffgpu_dwpw.inc); dw.out == pw.in is never written
 bool   ffgpu_dwpw_ok(const ConvDesc &dw, const ConvDesc &pw);
@@ -74,6 +74,11 @@ struct ExecParams {
     ffgpu_frame_dets *ring;   // record ring of the multi-GPU gather (ffgpu_exec_set_ring), or NULL
     int ring_slots, ring_stride;
     int bbox_max;             // NET.bbox_max of this forward: the reference re-reads it on every net_forward (ffcnn.c:461-463)
+    // u8 BGR frames of the net's own geometry, converted by the first kernel itself (k_front<.., true>; NULL: fp32 frames)
+    const unsigned char *bgr;
+    long  bgr_frame;          // bytes from one frame to the next
+    int   bgr_pitch;          // bytes per image row (ALIGN(3 w, 4), ffcnn.c:262)
+    float mean[3], norm[3];   // net_input's per-channel mean / norm (plane order R, G, B)
 };
 int  ffgpu_launch_set_params(ExecParams *d_prm, const ExecParams &v, hipStream_t s);
 bool ffgpu_conv_supports_ind(const ConvDesc &d);    // the kernel ffgpu_launch_conv would pick reads ConvDesc::in_ind

@@ -15,6 +15,7 @@
 //   * conv -> [dropout] -> shortcut: the residual add moves into the conv epilogue.
 #include <algorithm>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -161,7 +162,6 @@ struct ffgpu_netdev {
     size_t weight_bytes = 0;
     int    device = 0;
     ffgpu_exec *exec1 = nullptr;
-    void  *diag_registered = nullptr;  // TEMPORARY: see FFGPU_DIAG_REGISTER_INPUT
 };
 
 struct ffgpu_exec {
@@ -188,6 +188,10 @@ struct ffgpu_exec {
     const float *last_frames = nullptr;   // input of the last forward (read_layer(-1))
     ffgpu_frame_dets *d_dets = nullptr;
     ffgpu_frame_dets *h_dets = nullptr, *h_dets_dev = nullptr;   // FFGPU_HOST_DETS: pinned mirror and its device address
+    // u8 BGR frames converted by the first kernel itself (ffgpu_exec_forward_bgr_dev without resize on a plan that starts with k_front)
+    const unsigned char *bgr = nullptr; long bgr_frame = 0; int bgr_pitch = 0; float bgr_mean[3] = {}, bgr_norm[3] = {};
+    bool u8_mode = false;              // the forward being enqueued / captured reads `bgr`
+    hipGraphExec_t graph_u8 = nullptr; // its graph (the u8 form of the first kernel is another kernel): captured on first use
     float *h_stage = nullptr;          // ffgpu_exec_forward_host from caller memory: page-locked staging of one batch (on first use)
     ffgpu_frame_dets *ring = nullptr; int ring_slots = 0; int *d_ringctr = nullptr;   // ffgpu_exec_set_ring
     int ring_stride = 0;               // records per ring slot (the parent's batch for the halves of a split executor)
@@ -372,7 +376,13 @@ static int plan(ffgpu_exec *ex)
     // (not inside the halves of a split executor: a fork nested in a forked stream crashes graph capture on ROCm 7.0,
     //  and the second half-batch chain already fills the gaps the head branch was meant to fill)
     //  nor in an FFGPU_CONCURRENT plan: the other chains fill those gaps -- 0.489 vs 0.455 ms with the branch on)
-    const bool branch = (getenv("FFGPU_BRANCH") ? atoi(getenv("FFGPU_BRANCH")) != 0 : !(ex->flags & FFGPU_CONCURRENT)) && !ex->is_child;
+    //  Round 3: OPT-IN (FFGPU_BRANCH=1).  A graph with a forked branch makes the runtime (ROCm 7.0) run it on internal streams of
+    //  its own, and that part of the runtime is the fragile one: it kept an arena's worth of memory per destroyed graph until a
+    //  device-wide sync was put in front of hipGraphExecDestroy (ffgpu_exec_destroy), and the one host crash that survived the
+    //  round-3 transfer rework (SIGSEGV inside hipGraphLaunch of a freshly created executor, once in 30
+    //  runs of 630 create / launch / destroy cycles each) was in its walk over those streams.  2 % of ONE chain's latency is not
+    //  worth a process; throughput configurations (several chains, FFGPU_CONCURRENT) never used the branch.
+    const bool branch = (getenv("FFGPU_BRANCH") ? atoi(getenv("FFGPU_BRANCH")) != 0 : false) && !ex->is_child;
     if (fuse && branch) {
         for (int y = 0; y + 1 < L; y++) {
             if (ll[y].type != LAYER_TYPE_YOLO || ll[y + 1].type != LAYER_TYPE_ROUTE || ll[y + 1].depend_num != 1) continue;
@@ -685,7 +695,7 @@ static int issue_step(ffgpu_exec *ex, const Step &st, const float *d_frames, hip
     case S_FRONT: {
         ConvDesc d = st.conv;
         if (st.in_is_input && !d.in_ind) d.in = d_frames;
-        return ffgpu_launch_front(d, st.irb, s); }
+        return ffgpu_launch_front(d, st.irb, s, ex->u8_mode); }
     case S_YOLO:
         return ffgpu_launch_yolo(st.head, ex->N, ex->in_w, ex->in_h, ex->d_cand, ex->d_cand_key, ex->d_ncand, ex->cand_cap,
                                  st.flag ? ex->d_ringctr : nullptr, s);          // forwards are counted whether or not a ring is attached
@@ -700,7 +710,9 @@ static int issue_all(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
 {
     bool forked = false, joined = true;
     for (const Step &st : ex->steps) {
-        if (st.lane == 1 && ex->side_stream) {
+        if (st.lane == 1) {
+            // (the branch's stream exists only in plans that have one: every stream takes a share of the device's four hardware queues)
+            if (!ex->side_stream) FFGPU_CHECK(hipStreamCreateWithFlags(&ex->side_stream, hipStreamNonBlocking));
             if (!forked) {                                   // fork: the side branch starts where the main one is now
                 FFGPU_CHECK(hipEventRecord(ex->ev_fork, s));
                 FFGPU_CHECK(hipStreamWaitEvent(ex->side_stream, ex->ev_fork, 0));
@@ -748,8 +760,11 @@ static int push_params(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
     if (ex->child[0]) {
         const size_t part = (size_t)ex->child[0]->N * ex->in_c * ex->in_h * ex->in_w;
         for (int c = 0; c < ex->nchild; c++) {
-            ex->child[c]->s1 = ex->s1; ex->child[c]->s2 = ex->s2; ex->child[c]->bbox_max = ex->bbox_max; ex->child[c]->last_stream = s;
-            if (push_params(ex->child[c], d_frames + c * part, s)) return -1;
+            ffgpu_exec *ch = ex->child[c];
+            ch->s1 = ex->s1; ch->s2 = ex->s2; ch->bbox_max = ex->bbox_max; ch->last_stream = s;
+            ch->u8_mode = ex->u8_mode; ch->bgr = ex->bgr ? ex->bgr + (long)c * ch->N * ex->bgr_frame : nullptr; ch->bgr_frame = ex->bgr_frame; ch->bgr_pitch = ex->bgr_pitch;
+            memcpy(ch->bgr_mean, ex->bgr_mean, sizeof ch->bgr_mean); memcpy(ch->bgr_norm, ex->bgr_norm, sizeof ch->bgr_norm);
+            if (push_params(ch, ex->u8_mode ? nullptr : d_frames + c * part, s)) return -1;
         }
         return 0;
     }
@@ -757,6 +772,10 @@ static int push_params(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
     ExecParams v;
     memset(&v, 0, sizeof v);
     v.frames = d_frames; v.s1 = ex->s1; v.s2 = ex->s2;
+    if (ex->u8_mode) {
+        v.bgr = ex->bgr; v.bgr_frame = ex->bgr_frame; v.bgr_pitch = ex->bgr_pitch;
+        for (int k = 0; k < 3; k++) { v.mean[k] = ex->bgr_mean[k]; v.norm[k] = ex->bgr_norm[k]; }
+    }
     v.bbox_max = ex->bbox_max;
     v.ring = ex->ring; v.ring_slots = ex->ring_slots; v.ring_stride = ex->ring_stride ? ex->ring_stride : ex->N;
     if (ex->prm_valid && ex->prm_stream == s && memcmp(&v, &ex->prm_sent, sizeof v) == 0) return 0;
@@ -795,6 +814,7 @@ static int capture(ffgpu_exec *ex, const float *d_frames, hipGraphExec_t *out)
 static void drop_graphs(ffgpu_exec *ex)                       // caller has synchronised the streams the graphs ran on
 {
     if (ex->graph1) { (void)hipGraphExecDestroy(ex->graph1); ex->graph1 = nullptr; }
+    if (ex->graph_u8) { (void)hipGraphExecDestroy(ex->graph_u8); ex->graph_u8 = nullptr; }
     for (auto &g : ex->graphs) (void)hipGraphExecDestroy(g.g);
     ex->graphs.clear();
 }
@@ -816,8 +836,9 @@ static int forward_on(ffgpu_exec *ex, const float *d_frames, hipStream_t s)
     if (push_params(ex, d_frames, s)) return -1;
     if (ex->flags & FFGPU_NO_GRAPH) return ex->child[0] ? issue_split(ex, d_frames, s) : issue_all(ex, d_frames, s);
     if (graph_pointer_free(ex)) {                            // the usual case: one graph, whatever the input buffer / scale
-        if (!ex->graph1 && capture(ex, d_frames, &ex->graph1)) return -1;
-        FFGPU_CHECK(hipGraphLaunch(ex->graph1, s));
+        hipGraphExec_t &g1 = ex->u8_mode ? ex->graph_u8 : ex->graph1;      // (+ one more when u8 frames go straight into the first kernel)
+        if (!g1 && capture(ex, d_frames, &g1)) return -1;
+        FFGPU_CHECK(hipGraphLaunch(g1, s));
         return 0;
     }
     // fallback (the first layer's kernel cannot read through the parameter block): graphs keyed by the input pointer
@@ -899,7 +920,6 @@ static ffgpu_exec *exec_create_on(ffgpu_netdev *dev, NET *net, int batch, int fl
     while (cap_p2 < ex->cand_cap) cap_p2 <<= 1;
     const size_t ncs = (size_t)ex->cand_cap * (size_t)batch;
     bool ok = hipStreamCreateWithFlags(&ex->own_stream, hipStreamNonBlocking) == hipSuccess
-           && hipStreamCreateWithFlags(&ex->side_stream, hipStreamNonBlocking) == hipSuccess
            && hipEventCreateWithFlags(&ex->ev_fork, hipEventDisableTiming) == hipSuccess
            && hipEventCreateWithFlags(&ex->ev_join, hipEventDisableTiming) == hipSuccess
            && hipMalloc(&ex->d_cand, sizeof(BBOX) * ncs) == hipSuccess
@@ -1078,18 +1098,41 @@ extern "C" int ffgpu_exec_forward_host(ffgpu_exec *ex, const float *h_frames)
     return 0;
 }
 
+// the plan's first launch is k_front reading through the parameter block (every leaf of a split executor alike)
+static bool front_reads_u8(const ffgpu_exec *ex)
+{
+    if (ex->child[0]) {
+        for (int c = 0; c < ex->nchild; c++) if (!front_reads_u8(ex->child[c])) return false;
+        return true;
+    }
+    for (const Step &st : ex->steps)
+        if (st.in_is_input) return st.kind == S_FRONT && st.conv.in_ind != nullptr && ex->indirect;
+    return false;
+}
+
 extern "C" int ffgpu_exec_forward_bgr_dev(ffgpu_exec *ex, const unsigned char *d_bgr, int w, int h,
                                           const float mean[3], const float norm[3], void *stream)
 {
     if (!alive(ex, "forward_bgr_dev")) return -1;
     if (!d_bgr || w <= 0 || h <= 0 || ex->in_c != 3) { ffgpu_set_error("forward_bgr_dev: bad arguments"); return -1; }
-    if (ensure_input(ex)) return -1;
     hipStream_t s = stream ? (hipStream_t)stream : ex->own_stream;
     const int W = ex->in_w, H = ex->in_h;
     int sw, sh, s1, s2;                                          // ffcnn.c:267-273
     if ((long)w * H > (long)h * W) { sw = W; sh = (int)((long)sw * h / w); s1 = w; s2 = sw; }
     else                           { sh = H; sw = (int)((long)sh * w / h); s1 = h; s2 = sh; }
     ex->s1 = s1; ex->s2 = s2;
+    const bool no_u8_front = getenv("FFGPU_NO_U8_FRONT") != nullptr;             // (tuning / tests: always the two-kernel path)
+    if (w == W && h == H && (reinterpret_cast<uintptr_t>(d_bgr) & 7) == 0 && !no_u8_front && front_reads_u8(ex)) {
+        // no resize (net_input copies pixel for pixel): the first kernel converts the bytes itself -- no fp32 batch in between
+        const int pitch = (w * 3 + 3) & ~3;
+        ex->bgr = d_bgr; ex->bgr_pitch = pitch; ex->bgr_frame = (long)pitch * h;
+        for (int k = 0; k < 3; k++) { ex->bgr_mean[k] = mean[k]; ex->bgr_norm[k] = norm[k]; }
+        ex->u8_mode = true;
+        const int rc = forward_on(ex, nullptr, s);
+        ex->u8_mode = false;
+        return rc;
+    }
+    if (ensure_input(ex)) return -1;
     if (ffgpu_launch_input_bgr(d_bgr, ex->d_input, ex->N, w, h, W, H, sw, sh, s1, s2, mean, norm, s)) return -1;
     return forward_on(ex, ex->d_input, s);
 }
@@ -1184,6 +1227,7 @@ extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float
     }
     if (layer == -1) {                                            // the network input as the first layer saw it (frame-major)
         const size_t fl = (size_t)ex->in_c * ex->in_h * ex->in_w;
+        if (!ex->last_frames && ex->bgr) { ffgpu_set_error("read_layer: the last forward's frames were u8 images converted by the first kernel -- no fp32 input tensor exists"); return -1; }
         if (!ex->last_frames) { ffgpu_set_error("read_layer: no forward has run yet"); return -1; }
         if (fl > cap_floats) { ffgpu_set_error("read_layer: buffer too small"); return -1; }
         if (copy_d2h(host_out, ex->last_frames + (size_t)frame * fl, fl * sizeof(float))) return -1;
@@ -1327,7 +1371,6 @@ extern "C" void ffgpu_netdev_destroy(void *p)
     ffgpu_netdev *dev = (ffgpu_netdev *)p;
     if (!dev) return;
     if (dev->exec1) { ffgpu_exec_destroy(dev->exec1); dev->exec1 = nullptr; }
-    if (dev->diag_registered) { (void)hipHostUnregister(dev->diag_registered); dev->diag_registered = nullptr; }
     // executors the caller still holds outlive the net as orphans: their steps point into d_weights and the layer table,
     // so they wait for their streams here and from now on refuse to run (alive()); ffgpu_exec_destroy still frees them
     std::vector<ffgpu_exec *> left;
@@ -1353,11 +1396,6 @@ extern "C" int ffgpu_netdev_forward1(NET *net, void *p, int profile)
         // input tensor the application fills is page-locked memory of the runtime since net_load (ffgpu_host_alloc): one DMA up
         dev->exec1 = ffgpu_exec_create(net, 1, FFGPU_HOST_DETS);
         if (!dev->exec1) return -1;
-        if (getenv("FFGPU_DIAG_REGISTER_INPUT")) {               // TEMPORARY (round-3 diagnosis of GPUTEST_r02's abort): round 2's behaviour
-            const LAYER *l0 = net->layer_list;
-            if (hipHostRegister(l0->data, sizeof(float) * (size_t)l0->c * l0->h * l0->w, hipHostRegisterDefault) == hipSuccess) dev->diag_registered = l0->data;
-            else (void)hipGetLastError();
-        }
     }
     ffgpu_exec *ex = dev->exec1;
     ex->s1 = net->s1 ? net->s1 : 1;

@@ -192,6 +192,9 @@ int         ffgpu_node_forward_host(ffgpu_node *node, const float *h_frames, ffg
  * page-locked staging buffer before submit returns: the caller's buffer is free again at once. */
 long        ffgpu_node_submit(ffgpu_node *node, const float *h_frames);
 int         ffgpu_node_wait(ffgpu_node *node, long ticket, ffgpu_frame_dets *host_out);
+/* The loop above as one call: `steps` steps from the slots' input buffers, `depth` of them in flight (collect step i - depth,
+ * submit step i), every step's records brought to the host; host_out (may be NULL) receives the last step's. */
+int         ffgpu_node_run(ffgpu_node *node, long steps, ffgpu_frame_dets *host_out);
 
 /* ---- single operators on device tensors (CNHW, any batch) --------------- */
 /* Counterpart of groupconv (conv.h:4-7) without the host round trip.  d_in is
