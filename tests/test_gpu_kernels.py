@@ -166,8 +166,12 @@ def test_dw5_channel_pairs(env, orc, shape, pair, monkeypatch):
 # tiles (300, 255), sigmoid
 @pytest.mark.parametrize("shape", [(256, 512, 2, 20, 20, 2), (128, 255, 1, 20, 20, 0), (64, 130, 3, 10, 10, 2), (100, 200, 1, 12, 12, 1),
                                    (72, 300, 83, 20, 20, 2), (64, 256, 164, 20, 20, 0), (80, 255, 170, 20, 20, 3)])
-def test_pw_gemm(env, orc, shape):
+@pytest.mark.parametrize("wm", [0, 4, 8])
+def test_pw_gemm(env, orc, shape, wm, monkeypatch):
+    """wm: the workgroup form -- 0 = the launcher's choice (8 waves / 256-channel tiles from 248 filters up, else 4 waves / 128), or forced"""
     capi, torch = env
+    if wm:
+        monkeypatch.setenv("FFGPU_PWG_WM", str(wm))
     ic, oc, N, H, W, act = shape
     rng = np.random.default_rng(hash(shape) & 0xffff)
     x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
