@@ -21,7 +21,7 @@ for name, rng in SEG:
     else:
         os.environ.pop("FFGPU_DBG_SKIP", None)
     exs = [net.executor(64, capi.FFGPU.HOST_DETS | capi.FFGPU.CONCURRENT) for _ in range(4)]
-    sts = [torch.cuda.Stream() for _ in range(4)]
+    sts = [torch.cuda.Stream(priority=-1) for _ in range(4)]
     def run(k):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
