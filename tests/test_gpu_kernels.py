@@ -190,6 +190,10 @@ IGEMM_SHAPES = [  # (ic, oc, N, H, W, fs, stride, pad, act)
     (16, 32, 2, 24, 20, 3, 1, 1, 2), (32, 64, 1, 13, 13, 3, 1, 1, 2), (64, 130, 3, 7, 9, 3, 1, 1, 0), (8, 21, 2, 12, 8, 5, 1, 2, 0),
     (24, 48, 2, 17, 15, 3, 2, 1, 2), (12, 8, 1, 11, 11, 5, 2, 1, 1), (20, 10, 2, 9, 9, 3, 1, 0, 1), (128, 256, 1, 6, 4, 3, 1, 1, 2),
     (40, 70, 1, 5, 5, 1, 1, 0, 3), (9, 5, 3, 3, 3, 2, 1, 0, 2), (256, 160, 4, 6, 4, 3, 1, 1, 2), (16, 16, 1, 1, 1, 3, 1, 1, 2),
+    # round 3: the quad-gather form (3x3 s1 p1, ow % 4 == 0): both tile shapes, ragged K (10 and 13 channels: 90 / 117 = 3.75 / 4.9 chunks
+    # of 24), one-row and four-column planes (every quad touches both borders), ragged channel tiles, a tile count beyond one round
+    (10, 24, 2, 8, 8, 3, 1, 1, 2), (13, 100, 1, 5, 12, 3, 1, 1, 0), (8, 64, 3, 1, 4, 3, 1, 1, 2), (32, 33, 2, 16, 4, 3, 1, 1, 1),
+    (16, 32, 3, 52, 52, 3, 1, 1, 2), (64, 128, 2, 26, 28, 3, 1, 1, 3), (24, 200, 5, 20, 20, 3, 1, 1, 2),
 ]
 
 
