@@ -197,11 +197,14 @@ IGEMM_SHAPES = [  # (ic, oc, N, H, W, fs, stride, pad, act)
 ]
 
 
+@pytest.mark.parametrize("split", [0, 3])
 @pytest.mark.parametrize("shape", IGEMM_SHAPES)
-def test_conv_igemm(env, orc, shape):
+def test_conv_igemm(env, orc, shape, split, monkeypatch):
     """dense KxK as implicit GEMM (k_conv_igemm: both tile shapes, ragged K / channels / pixels, odd pixel counts, stride 2,
     pad 0, 5x5, 2x2, 1x1, sigmoid) against the generic kernel and, frame by frame, the oracle"""
     capi, torch = env
+    if split:                                                       # split-K forced (3 parts, or one per chunk): partial sums + the reduction kernel
+        monkeypatch.setenv("FFGPU_IGEMM_SPLIT", str(split))
     ic, oc, N, H, W, fs, stride, pad, act = shape
     rng = np.random.default_rng(hash(shape) & 0xffff)
     x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
