@@ -194,6 +194,9 @@ IGEMM_SHAPES = [  # (ic, oc, N, H, W, fs, stride, pad, act)
     # of 24), one-row and four-column planes (every quad touches both borders), ragged channel tiles, a tile count beyond one round
     (10, 24, 2, 8, 8, 3, 1, 1, 2), (13, 100, 1, 5, 12, 3, 1, 1, 0), (8, 64, 3, 1, 4, 3, 1, 1, 2), (32, 33, 2, 16, 4, 3, 1, 1, 1),
     (16, 32, 3, 52, 52, 3, 1, 1, 2), (64, 128, 2, 26, 28, 3, 1, 1, 3), (24, 200, 5, 20, 20, 3, 1, 1, 2),
+    # ... and widths that are not multiples of 4 (rows padded to quads; the last quad of a row shifts the row's last four columns)
+    (16, 40, 2, 13, 13, 3, 1, 1, 2), (32, 64, 3, 26, 26, 3, 1, 1, 2), (8, 16, 1, 5, 5, 3, 1, 1, 0), (12, 70, 2, 3, 7, 3, 1, 1, 1),
+    (8, 9, 2, 9, 6, 3, 1, 1, 2), (64, 96, 1, 13, 13, 3, 1, 1, 2), (9, 130, 4, 4, 4, 3, 1, 1, 2),
 ]
 
 
