@@ -409,7 +409,8 @@ def main():
     # chain streams are PRIORITY streams: the runtime keeps a pool of (at most four) hardware queues per priority level, so the four
     # chains get queues of their own whatever other streams the process holds (torch's, RCCL's) -- at the default priority which chains
     # end up behind each other on one hardware queue depends on how many streams were created before them
-    prio = int(os.environ.get("FFCNN_BENCH_STREAM_PRIORITY", "-1"))
+    prios = [int(v) for v in os.environ.get("FFCNN_BENCH_STREAM_PRIORITY", "-1").split(",")]      # (a list: chain j takes prios[j % len])
+    prio = prios[0]
     stream = torch.cuda.Stream(priority=prio)
     roof = roof_pw = None
     net = capi.Net()
@@ -449,7 +450,7 @@ def main():
     if S >= 3:
         flags |= capi.FFGPU.CONCURRENT      # plan for throughput: several chains fill the device together
     exs = [net.executor(Bx, flags) for _ in range(S)]
-    streams = [stream] + [torch.cuda.Stream(priority=prio) for _ in range(S - 1)]
+    streams = [stream] + [torch.cuda.Stream(priority=prios[j % len(prios)]) for j in range(1, S)]
     ex = exs[0]
     model_bytes, model_flops = ex.work_model()
 
