@@ -111,4 +111,5 @@ int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap,
                      ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, const int *ring_ctr, int N,
                      float thresh, int use_min, const ExecParams *prm, hipStream_t s);
 #define FFGPU_NMS_LDS_CAP 8192
+bool ffgpu_nms_in_lds(int cap_pow2);      // the work arrays of cap_pow2 slots fit the CURRENT device's LDS (else: global scratch, 13 bytes per slot and frame)
 int ffgpu_launch_clear(int *ncand, int N, int *ring_ctr, hipStream_t s);

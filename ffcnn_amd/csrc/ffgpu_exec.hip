@@ -926,7 +926,7 @@ static ffgpu_exec *exec_create_on(ffgpu_netdev *dev, NET *net, int batch, int fl
            && hipMalloc(&ex->d_cand_key, sizeof(int) * ncs) == hipSuccess
            && hipMalloc(&ex->d_full, sizeof(BBOX) * ncs) == hipSuccess
            && hipMalloc(&ex->d_prm, sizeof(ExecParams)) == hipSuccess && hipMemset(ex->d_prm, 0, sizeof(ExecParams)) == hipSuccess
-           && (cap_p2 <= FFGPU_NMS_LDS_CAP || hipMalloc(&ex->d_nms_scratch, (size_t)13 * cap_p2 * batch) == hipSuccess)
+           && (ffgpu_nms_in_lds(cap_p2) || hipMalloc(&ex->d_nms_scratch, (size_t)13 * cap_p2 * batch) == hipSuccess)
            && hipMalloc(&ex->d_ncand, sizeof(int) * (size_t)batch) == hipSuccess && hipMemset(ex->d_ncand, 0, sizeof(int) * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_dets, sizeof(ffgpu_frame_dets) * (size_t)batch) == hipSuccess
            && hipMalloc(&ex->d_ringctr, sizeof(int)) == hipSuccess && hipMemset(ex->d_ringctr, 0, sizeof(int)) == hipSuccess

@@ -607,13 +607,22 @@ int ffgpu_launch_yolo(const YoloHead &hd, int N, int netw, int neth, BBOX *cand,
     return 0;
 }
 
+bool ffgpu_nms_in_lds(int cap_pow2)
+{
+    if (cap_pow2 > FFGPU_NMS_LDS_CAP) return false;
+    int dev = 0, lds = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds <= 0) { (void)hipGetLastError(); lds = 64 * 1024; }
+    return (size_t)13 * cap_pow2 <= (size_t)lds;      // (gfx950: 160 KB -- up to 8192 slots; a 64 KB part: 4096)
+}
+
 int ffgpu_launch_nms(const BBOX *cand, const int *cand_key, int *ncand, int cap, BBOX *full, void *scratch,
                      ffgpu_frame_dets *dets, ffgpu_frame_dets *dets_host, const int *ring_ctr, int N,
                      float thresh, int use_min, const ExecParams *prm, hipStream_t s)
 {
     int p2 = 1;
     while (p2 < cap) p2 <<= 1;
-    if (p2 > FFGPU_NMS_LDS_CAP) {
+    if (!ffgpu_nms_in_lds(p2)) {
         if (!scratch) { ffgpu_set_error("nms: %d candidate slots per frame need the global scratch buffer", cap); return -1; }
         hipLaunchKernelGGL(k_nms<true>, dim3(N), dim3(256), 0, s, cand, cand_key, ncand, cap, p2, full, (unsigned char *)scratch,
                            dets, dets_host, ring_ctr, thresh, use_min, prm);
