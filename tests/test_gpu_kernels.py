@@ -224,6 +224,34 @@ def test_conv_igemm(env, orc, shape, split, monkeypatch):
         check(got.reshape(oc, N, OH, OW)[:, n], o, "conv_igemm %s frame %d vs oracle" % (shape, n))
 
 
+THIN_SHAPES = [  # (ic, oc, groups, N, H, W, fs, stride, pad, act): 2..7 input channels per group
+    (8, 8, 4, 2, 9, 11, 3, 1, 1, 2), (12, 24, 4, 1, 13, 13, 3, 1, 1, 2), (64, 64, 16, 3, 20, 20, 3, 1, 1, 2), (28, 16, 4, 2, 7, 5, 5, 1, 2, 0),
+    (6, 9, 3, 2, 17, 16, 3, 2, 1, 1), (10, 30, 2, 1, 8, 8, 1, 1, 0, 3), (21, 35, 7, 2, 6, 6, 3, 1, 0, 2), (4, 5, 1, 2, 10, 9, 2, 1, 0, 2),
+    (7, 8, 1, 1, 5, 5, 7, 1, 3, 2), (32, 8, 8, 2, 1, 1, 3, 1, 1, 0), (48, 48, 8, 1, 40, 40, 3, 1, 1, 2), (6, 2, 2, 3, 300, 1, 3, 1, 1, 2),
+]
+
+
+@pytest.mark.parametrize("shape", THIN_SHAPES)
+def test_conv_thin_groups(env, orc, shape):
+    """grouped (and thin dense) convolutions with 2..7 input channels per group on k_conv_thin (scalar filter taps, several outputs
+    per lane; conv-v0.c:7-31, 46-51): against the generic kernel -- the same k-ordered fmaf chain, so equal to the last bit where no
+    product is a signed zero -- and, frame by frame, the oracle"""
+    capi, torch = env
+    ic, oc, groups, N, H, W, fs, stride, pad, act = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f = make_filter(rng, oc, fs * fs * ic // groups)
+    assert capi.kernel_name(N, W, H, ic, groups, pad, stride, fs, oc) == "conv_thin"
+    got = run_dev(capi, torch, x, f, N, W, H, ic, groups, pad, stride, fs, oc, act, capi.FFGPU.K_AUTO)
+    ref = run_dev(capi, torch, x, f, N, W, H, ic, groups, pad, stride, fs, oc, act, capi.FFGPU.K_GENERIC)
+    assert np.array_equal(got, ref), "conv_thin %s differs from the generic kernel (max |d| %.3g)" % (shape, np.abs(got - ref).max())
+    OH, OW = (H + 2 * pad - fs) // stride + 1, (W + 2 * pad - fs) // stride + 1
+    xf = x.reshape(ic, N, H, W)
+    for n in range(N):
+        o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, groups, pad, stride, fs, act)
+        check(got.reshape(oc, N, OH, OW)[:, n], o, "conv_thin %s frame %d vs oracle" % (shape, n))
+
+
 @pytest.mark.parametrize("shape", [(32, 48, 2, 2, 11, 9, 3, 1, 1, 2), (64, 64, 4, 1, 8, 8, 3, 2, 1, 2), (48, 24, 3, 3, 7, 7, 1, 1, 0, 0), (32, 160, 2, 1, 6, 10, 5, 1, 2, 1)])
 def test_conv_igemm_grouped(env, orc, shape):
     """grouped convolutions with >= 8 channels per group (conv-v0.c:46-51: group g uses its slice of input channels, filter
