@@ -234,7 +234,7 @@ def node_line(args, ngpus):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--node", "--gpus", str(ngpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--depth", "8"]                                      # (a host that waits for every step's records needs a deeper pipeline than the enqueue-only loop above)
     if args.global_batch > 0:
-        cmd += ["--global-batch", str(args.global_batch)]
+        cmd += ["--global-batch", str(args.global_batch)] + (["--merge-steps", str(args.merge_steps)] if args.merge_steps > 0 else [])
     try:
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -262,11 +262,19 @@ def run_node(args):
     strong = args.global_batch > 0
     G = args.global_batch if strong else FRAMES_PER_GPU * N
     D = max(1, min(args.depth, 8))
+    # strong scaling: as in main(), a launch takes the shards of MS consecutive steps (a 32-frame launch leaves the small planes short
+    # of waves): the node is created over MS * G frames, rank r's contiguous block = its shard of each of the MS steps behind each other
+    MS = 1
+    if strong:
+        if G % N:
+            raise SystemExit("--global-batch %d is not a multiple of %d GPUs" % (G, N))
+        MS = args.merge_steps if args.merge_steps > 0 else max(1, 128 // (G // N))
+    GL = MS * G                                                 # frames per launch (all devices)
     torch.cuda.set_device(0)
     capi.lib().ffgpu_set_device(0)
     os.environ.setdefault("FFGPU_BRANCH", "0" if D > 1 else "1")
     net = capi.Net()
-    nd = capi.Node(net, N, G, exec_flags=capi.FFGPU.CONCURRENT if D >= 3 else 0, node_flags=capi.Node.DEPTH(D))
+    nd = capi.Node(net, N, GL, exec_flags=capi.FFGPU.CONCURRENT if D >= 3 else 0, node_flags=capi.Node.DEPTH(D))
     nd.set_scale(640, 320)
     # synthetic frames: the same global stream as the torchrun job (seed 1236, frame 0 = letterboxed test.bmp); every slot of
     # every device holds its own batch, resident in HBM before the timed region (D x 78.6 MB per device > the Infinity Cache)
@@ -294,11 +302,11 @@ def run_node(args):
                     view[0] = img.to("cuda:%d" % dev)
     for d in range(N):
         torch.cuda.synchronize(d)
-    recs = np.zeros(G, capi.DETS_DTYPE)
+    recs = np.zeros(GL, capi.DETS_DTYPE)
 
     def run(nsteps):                                            # the pipelined loop itself runs in C (ffgpu_node_run), as a C host's would
         if nsteps > 0:
-            nd.run(nsteps, recs)
+            nd.run(-(-nsteps // MS), recs)                      # launches (a ragged last one still does MS steps)
 
     pre = max(D, 128 // D * D)                                  # the device's sustained clock state (see main(): ~40 ms of forwards)
     run(pre)
@@ -324,7 +332,8 @@ def run_node(args):
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "host": "C node API: one process, one host thread, ffgpu_node_run (= ffgpu_node_submit / ffgpu_node_wait, depth steps in flight) over include/ffcnn_hip.h",
            "config": {"workload": "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[%d])" % (4 if strong else 3),
-                      "frames_per_gpu": G // N, "global_batch": G, "parallelism": "dp%d" % N, "steps_in_flight": D,
+                      "frames_per_gpu": G // N, "global_batch": G, "parallelism": "dp%d" % N, "steps_in_flight": D * MS,
+                      "steps_per_launch": MS, "frames_per_launch": GL // N,
                       "exchange": "none (one device: the NMS kernel writes the records into pinned host memory)" if N == 1 else
                                   "ncclBroadcast of the weights at create; per step one grouped ncclSend/ncclRecv of the packed records per peer + one D2H",
                       "untimed_forwards_before_t0": pre + args.warmup,
@@ -680,8 +689,29 @@ def main():
             torch.cuda.synchronize()
             t8 = time.perf_counter() - t1
         out["config"]["u8_bgr_input"] = {"value": round(Bx * n8 / t8, 1), "unit": "frames/s", "steps": n8,
-                                         "what": "same job, %d u8 BGR 320x320 frames per step resident in HBM -> ffgpu_exec_forward_bgr_dev (batched net_input kernel + the net)" % B}
+                                         "what": "same job, %d u8 BGR 320x320 frames per step resident in HBM -> ffgpu_exec_forward_bgr_dev (images of the net's size: converted by the first kernel itself)" % B}
         del us
+        # ... and the same frames with TWO consecutive steps per launch (what the strong-scaling mode does with its shards): not the
+        # reported value -- BASELINE's config is a 64-frame batch per step and launch --, the headroom a serving loop has if it may
+        # put two batches into one launch
+        if MS == 1 and K_in >= 2:
+            ex2 = [net.executor(2 * Bx, flags) for _ in range(S)]
+            x2 = [torch.cat([xs[(2 * k) % K_in], xs[(2 * k + 1) % K_in]]) for k in range(max(1, K_in // 2))]
+            for e in ex2:
+                e.set_scale(640, 320)
+            n2 = max(S, min(args.steps, 200) // 2 // S * S)
+            for rep in range(2):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(n2):
+                    ex2[i % S].forward_dev(x2[i % len(x2)].data_ptr(), streams[i % S].cuda_stream)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter() - t1
+            out["config"]["two_steps_per_launch"] = {"value": round(2 * Bx * n2 / t2, 1), "unit": "frames/s", "launches": n2,
+                                                     "what": "untimed extra: 128 frames (two steps' batches) per launch on the same %d chains; NOT the reported configuration" % S}
+            for e in ex2:
+                e.close()
+            del x2
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         for e in exs:
             e.close()
