@@ -63,7 +63,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_kernel_count", "ffgpu_exec_work_model", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
            "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_set_ring", "ffgpu_exec_set_ring_strided", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
            "ffgpu_exec_read_boxes", "ffgpu_exec_cand_capacity", "ffgpu_exec_graph_captures",
-           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_dwpw_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records",
+           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_dwpw_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records", "ffgpu_unpack_records",
            "ffgpu_shard_range", "ffgpu_node_create", "ffgpu_node_destroy", "ffgpu_node_ndev", "ffgpu_node_shard", "ffgpu_node_set_scale",
            "ffgpu_node_input_dev", "ffgpu_node_input_slot_dev", "ffgpu_node_depth", "ffgpu_node_forward", "ffgpu_node_forward_host",
            "ffgpu_node_submit", "ffgpu_node_wait", "ffgpu_node_run"]
@@ -164,6 +164,7 @@ def lib():
     L.ffgpu_node_submit.argtypes = [vp, f32p]
     L.ffgpu_node_wait.argtypes = [vp, C.c_long, vp]
     L.ffgpu_node_run.argtypes = [vp, C.c_long, vp]
+    L.ffgpu_unpack_records.argtypes = [vp, i, i, vp]
     L.ffgpu_node_forward.argtypes = [vp, vp]
     L.ffgpu_node_forward_host.argtypes = [vp, f32p, vp]
     _lib = L

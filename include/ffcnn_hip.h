@@ -253,6 +253,10 @@ float ffgpu_dwpw_dev(const float *d_in, const float *d_wd, const float *d_wp, fl
  * boxes of the frames behind each other in frame order (a frame's first box sits at the sum of the counts before it).  A step with more than `cap` boxes keeps the first `cap`
  * (over = 1, overflow |= 2 on the frames that lost boxes).  ffcnn_amd/dist.py unpacks them on the host. */
 size_t ffgpu_packed_records_bytes(int batch, int cap);
+/* host side: one packed block -> `batch` fixed-size records (unused box slots zero, as the NMS kernel leaves them).  Returns 0, or 1
+ * if the block had dropped boxes / does not describe (batch, cap) -- the caller then fetches the full-size records --, -1 on bad arguments.
+ * Pure host code (what ffgpu_node_wait runs on the gathered blocks). */
+int    ffgpu_unpack_records(const void *block, int batch, int cap, ffgpu_frame_dets *out);
 int    ffgpu_pack_records(const void *d_records, int nslots, long slot_stride_records, int batch, int cap, void *d_out, void *stream);
 
 #ifdef __cplusplus

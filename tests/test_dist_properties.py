@@ -120,3 +120,41 @@ def test_merge_restores_global_frame_order(world, total, seed):
         bufs.append(b.tobytes())
     merged = ffdist.merge_records(bufs, [hi - lo for lo, hi in shards], capi.DETS_DTYPE)
     assert np.array_equal(merged, allrec)
+
+
+def test_c_unpack_of_packed_records_is_the_inverse_of_packing():
+    """ffgpu_unpack_records (host code of the C node path: what ffgpu_node_wait runs on the gathered blocks) against the numpy mirror of
+    the device packer (tests/packref.py) and the Python unpacker of the torchrun path: random record sets round-trip byte for byte;
+    a block that had to drop boxes, or one of another (batch, cap), is reported (1) so that the caller fetches the full records"""
+    import ctypes as C
+    from ffcnn_amd import capi
+    from ffcnn_amd import dist as ffdist
+    from packref import pack_records
+    L = capi.lib()
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        batch = int(rng.integers(1, 40))
+        recs = np.zeros(batch, capi.DETS_DTYPE)
+        for n in range(batch):
+            k = int(rng.integers(0, 6)) if rng.random() < 0.8 else int(rng.integers(0, capi.FFGPU.MAX_DET + 1))
+            recs[n]["count"] = k
+            recs[n]["ncand"] = k + int(rng.integers(0, 50))
+            recs[n]["overflow"] = int(rng.integers(0, 2)) * 4
+            recs[n]["nfull"] = k + int(rng.integers(0, 3))
+            for f in ("score", "x1", "y1", "x2", "y2"):
+                recs[n]["box"][f][:k] = rng.uniform(0, 300, k)
+            recs[n]["box"]["type"][:k] = rng.integers(0, 80, k)
+        total = int(recs["count"].sum())
+        for cap in (max(1, total), total + 7, max(1, total // 2)):
+            blk = pack_records(recs, cap)
+            out = np.zeros(batch, capi.DETS_DTYPE)
+            out["count"] = -7                                         # (every field must be written)
+            rc = L.ffgpu_unpack_records(blk.ctypes.data, batch, cap, out.ctypes.data)
+            if cap >= total:
+                assert rc == 0 and out.tobytes() == recs.tobytes(), (trial, cap)
+                assert ffdist.unpack_records(blk, capi.DETS_DTYPE).tobytes() == recs.tobytes()
+            else:
+                assert rc == 1, (trial, cap, total)                   # boxes were dropped: fetch the full-size records instead
+        blk = pack_records(recs, total + 3)
+        assert L.ffgpu_unpack_records(blk.ctypes.data, batch + 1, total + 3, out.ctypes.data) == 1      # not a block of this (batch, cap)
+        assert L.ffgpu_unpack_records(None, batch, 4, out.ctypes.data) == -1
