@@ -232,11 +232,13 @@ def node_line(args, ngpus):
            if not (k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "GROUP_WORLD_SIZE",
                          "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") or k.startswith("TORCHELASTIC") or k.startswith("TORCH_NCCL"))}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--node", "--gpus", str(ngpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--depth", "8"]                                      # (a host that waits for every step's records needs a deeper pipeline than the enqueue-only loop above)
+           "--depth", "8" if ngpus == 1 else "4"]               # (a host that waits for every step's records needs a deeper pipeline than the
+                                                                #  enqueue-only loop above; N > 1: fewer executors to create inside the time limit)
     if args.global_batch > 0:
         cmd += ["--global-batch", str(args.global_batch)] + (["--merge-steps", str(args.merge_steps)] if args.merge_steps > 0 else [])
     try:
-        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+        # (bounded: at N > 1 this is the RCCL branch of the node path, which no box of rounds 1-3 could run; it must never cost the main line)
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=180)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
