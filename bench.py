@@ -231,7 +231,8 @@ def node_line(args, ngpus):
     env = {k: v for k, v in os.environ.items()
            if not (k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "GROUP_WORLD_SIZE",
                          "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") or k.startswith("TORCHELASTIC") or k.startswith("TORCH_NCCL"))}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--node", "--gpus", str(ngpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+    # (at least 400 steps whatever --steps is: with 8 steps in flight a 20-step run would be mostly fill and drain)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--node", "--gpus", str(ngpus), "--steps", str(max(args.steps, 400)), "--warmup", str(max(args.warmup, 40)),
            "--depth", "8" if ngpus == 1 else "4"]               # (a host that waits for every step's records needs a deeper pipeline than the
                                                                 #  enqueue-only loop above; N > 1: fewer executors to create inside the time limit)
     if args.global_batch > 0:
@@ -682,7 +683,7 @@ def main():
         out["roofline_net"]["single_chain_ms_per_batch"] = round((time.perf_counter() - t1) / nlat / MS * 1e3, 4)
         gu = torch.Generator(device="cuda").manual_seed(1236)
         us = [torch.randint(0, 256, (Bx, 320, 960), dtype=torch.uint8, device="cuda", generator=gu) for _ in range(K_in)]
-        n8 = max(S, min(args.steps, 200) // S * S)
+        n8 = 200 // S * S                                       # (its own length: an extra of a 20-step run is not a 20-step measurement)
         for rep in range(2):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -701,7 +702,7 @@ def main():
             x2 = [torch.cat([xs[(2 * k) % K_in], xs[(2 * k + 1) % K_in]]) for k in range(max(1, K_in // 2))]
             for e in ex2:
                 e.set_scale(640, 320)
-            n2 = max(S, min(args.steps, 200) // 2 // S * S)
+            n2 = max(S, 100 // S * S)
             for rep in range(2):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
