@@ -252,6 +252,32 @@ def test_conv_thin_groups(env, orc, shape):
         check(got.reshape(oc, N, OH, OW)[:, n], o, "conv_thin %s frame %d vs oracle" % (shape, n))
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_conv_thin_groups_random(env, seed):
+    """seeded random thin-group geometries (2..7 channels per group, 1..12 filters per group, filter sizes 1-7, strides 1-3, any
+    padding up to the filter size, planes from 1x1 to 70x40, residual on or off): k_conv_thin == k_conv_generic to the last bit"""
+    capi, torch = env
+    rng = np.random.default_rng(7100 + seed)
+    done = 0
+    while done < 16:
+        gic, goc, groups = int(rng.integers(2, 8)), int(rng.integers(1, 13)), int(rng.integers(1, 7))
+        fs, stride = int(rng.choice([1, 2, 3, 3, 5, 7])), int(rng.integers(1, 4))
+        pad = int(rng.integers(0, fs + 1))
+        N, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 41)), int(rng.integers(1, 71))
+        if H + 2 * pad < fs or W + 2 * pad < fs:
+            continue
+        ic, oc, act = gic * groups, goc * groups, int(rng.integers(0, 4))
+        if capi.kernel_name(N, W, H, ic, groups, pad, stride, fs, oc) != "conv_thin":
+            continue                                                 # (dense 3x3 / 5x5 with <= 8 channels belong to k_conv_dense8)
+        x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+        f = make_filter(rng, oc, fs * fs * gic)
+        got = run_dev(capi, torch, x, f, N, W, H, ic, groups, pad, stride, fs, oc, act, capi.FFGPU.K_AUTO)
+        ref = run_dev(capi, torch, x, f, N, W, H, ic, groups, pad, stride, fs, oc, act, capi.FFGPU.K_GENERIC)
+        assert np.array_equal(got, ref), "ic %d oc %d groups %d N %d %dx%d fs %d s %d p %d act %d: max |d| %.3g" % (
+            ic, oc, groups, N, H, W, fs, stride, pad, act, np.abs(got - ref).max())
+        done += 1
+
+
 @pytest.mark.parametrize("shape", [(32, 48, 2, 2, 11, 9, 3, 1, 1, 2), (64, 64, 4, 1, 8, 8, 3, 2, 1, 2), (48, 24, 3, 3, 7, 7, 1, 1, 0, 0), (32, 160, 2, 1, 6, 10, 5, 1, 2, 1)])
 def test_conv_igemm_grouped(env, orc, shape):
     """grouped convolutions with >= 8 channels per group (conv-v0.c:46-51: group g uses its slice of input channels, filter
