@@ -81,7 +81,13 @@ def pick_ref_lib():
 
 
 CPU_WORKER = r"""
-import sys, time
+import os, sys, time
+cpu = %(cpu)d
+if cpu >= 0:
+    try:
+        os.sched_setaffinity(0, {cpu})          # one process per PHYSICAL core: its first hardware thread
+    except (AttributeError, OSError):
+        pass
 sys.path.insert(0, %(root)r)
 from oracle import orc
 bgr, w, h = orc.load_bmp()
@@ -96,14 +102,32 @@ print(n, dt, r.n.bbox_num)
 """
 
 
-def cpu_baseline(secs=8.0):
-    """Reference CPU path on this box's host cores: 1 thread, then one process per core."""
-    variant, desc = pick_ref_lib()
-    ncpu = os.cpu_count() or 1
+def host_topology():
+    """(hardware threads this process may run on, one representative thread per PHYSICAL core among them).
+    Physical cores = distinct /sys/devices/system/cpu/cpuN/topology/thread_siblings_list values ("P = physical cores")."""
     try:
-        ncpu = len(os.sched_getaffinity(0))
+        allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:
-        pass
+        allowed = list(range(os.cpu_count() or 1))
+    cores = {}
+    for c in allowed:
+        key = None
+        for name in ("thread_siblings_list", "core_cpus_list"):
+            try:
+                key = open("/sys/devices/system/cpu/cpu%d/topology/%s" % (c, name)).read().strip()
+                break
+            except OSError:
+                continue
+        cores.setdefault(key if key is not None else "cpu%d" % c, []).append(c)
+    return allowed, sorted(min(v) for v in cores.values())
+
+
+def cpu_baseline(secs=8.0):
+    """Reference CPU path on this box's host cores: 1 thread, then one process per PHYSICAL core (threads reported beside it),
+    and the reference's own multi-threaded variant (conv-v4.c, the one OpenMP pragma of the repo: conv-v4.c:53) on as many threads."""
+    variant, desc = pick_ref_lib()
+    threads, reps = host_topology()
+    ncore = len(reps)
     if variant is None:
         # no reference build travelled: time the oracle port instead (slower, scalar)
         from oracle import orc
@@ -119,9 +143,9 @@ def cpu_baseline(secs=8.0):
         return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                 "sample": "%d frames of test.bmp at 320x320 through oracle/ffcnn_oracle.c (-O2), 1 thread, %.1f s" % (n, dt)}
 
-    def run(nproc):
-        code = CPU_WORKER % dict(root=ROOT, variant=variant, secs=secs)
-        procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True) for _ in range(nproc)]
+    def run(cpus, var=variant, env=None):
+        procs = [subprocess.Popen([sys.executable, "-c", CPU_WORKER % dict(root=ROOT, variant=var, secs=secs, cpu=c)],
+                                  stdout=subprocess.PIPE, text=True, env=env) for c in cpus]
         tot = 0.0
         frames = 0
         for p in procs:
@@ -131,18 +155,31 @@ def cpu_baseline(secs=8.0):
                 frames += int(out[0])
         return tot, frames
 
-    one, f1 = run(1)
-    allc, fa = run(ncpu) if ncpu > 1 else (one, f1)
+    one, f1 = run([-1])
+    allc, fa = run(reps) if ncore > 1 else (one, f1)
     model = ""
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except (OSError, IndexError):
         pass
-    return {"value": round(one, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
-            "sample": "%d frames (~%.0f s) of net_input+net_forward on test.bmp at 320x320, reference ffcnn.c+conv-v6.c "
-                      "built %s, 1 thread" % (f1, secs, desc),
-            "all_cores": {"value": round(allc, 3), "cores": ncpu, "how": "%d independent processes, one NET each" % ncpu},
-            "cpu": model}
+    out = {"value": round(one, 3), "unit": "frames/s", "cores": 1, "kind": "reference",
+           "sample": "%d frames (~%.0f s) of net_input+net_forward on test.bmp at 320x320, reference ffcnn.c+conv-v6.c "
+                     "built %s, 1 thread" % (f1, secs, desc),
+           "all_cores": {"value": round(allc, 3), "cores": ncore, "threads": len(threads),
+                         "how": "%d independent processes (one NET each), one per physical core, each pinned to its core's first hardware thread; "
+                                "%d hardware threads visible" % (ncore, len(threads))},
+           "cpu": model}
+    # the reference's own threaded variant: conv-v4.c with OMP_NUM_THREADS = physical cores (one process, one NET)
+    v4 = "v4_fast_v3"
+    if {"avx2", "fma", "bmi2"} <= cpu_flags() and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libffcnn_ref_%s.so" % v4)):
+        try:
+            env = dict(os.environ, OMP_NUM_THREADS=str(ncore), OMP_PROC_BIND="close", OMP_PLACES="cores")
+            r4, f4 = run([-1], var=v4, env=env)
+            out["openmp_v4"] = {"value": round(r4, 3), "unit": "frames/s", "cores": ncore, "threads": ncore,
+                                "how": "reference ffcnn.c+conv-v4.c (-Ofast -march=x86-64-v3 -fopenmp), one process, OMP_NUM_THREADS=%d, %d frames" % (ncore, f4)}
+        except Exception as e:                                  # noqa: BLE001 -- an extra
+            out["openmp_v4"] = {"error": repr(e)[:200]}
+    return out
 
 
 def kernel_roofline(torch, capi, stream):
@@ -226,25 +263,73 @@ def pw_roofline(torch, capi, stream):
             "workload": "pw1x1 256->512 20x20 batch 256 fp32 (BASELINE config[2])"}
 
 
+def launch_plan(gpus, env, ndev, node=False):
+    """How `bench.py --gpus N` runs, decided from the command line, the environment and the visible devices alone:
+         ("inline", None)    this process is the job (N = 1), or one rank of a torchrun job whose WORLD_SIZE == N
+         ("node", None)      --node: the C node path, one process for all N devices
+         ("torchrun", None)  N > 1 without a launcher: re-exec under torch.distributed.run, one rank per GPU
+                             (FFCNN_BENCH_MULTI=node takes the C node path instead)
+         ("refuse", why)     anything that would measure fewer than N GPUs and label it N (or label N GPUs as 1): rc != 0
+       `--gpus N` uses N GPUs however it is launched, or fails loudly ("What's missing" 1)."""
+    if gpus < 1:
+        return "refuse", "--gpus %d" % gpus
+    if node:
+        if int(env.get("WORLD_SIZE", "1")) > 1:
+            return "refuse", "--node is one process for all GPUs: do not launch it under torchrun"
+        if ndev < gpus:
+            return "refuse", "--gpus %d but %d HIP devices visible" % (gpus, ndev)
+        return "node", None
+    if "WORLD_SIZE" in env:
+        try:
+            world = int(env["WORLD_SIZE"])
+        except ValueError:
+            return "refuse", "WORLD_SIZE=%r" % env["WORLD_SIZE"]
+        if world != gpus:
+            return "refuse", "--gpus %d but WORLD_SIZE=%d: the line would be labelled with a GPU count the job does not have" % (gpus, world)
+        if ndev < int(env.get("LOCAL_WORLD_SIZE", world)):
+            return "refuse", "--gpus %d (WORLD_SIZE=%d) but %d HIP devices visible" % (gpus, world, ndev)
+        return "inline", None
+    if gpus == 1:
+        return ("inline", None) if ndev >= 1 else ("refuse", "bench.py needs a HIP device (no CPU fallback)")
+    if ndev < gpus:
+        return "refuse", "--gpus %d but %d HIP device%s visible: refusing to run a %d-GPU job on fewer devices" % (gpus, ndev, "" if ndev == 1 else "s", gpus)
+    return ("node", None) if env.get("FFCNN_BENCH_MULTI", "torchrun") == "node" else ("torchrun", None)
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def node_budget_s(ngpus, depth):
+    """time limit of the `--node` child: creating an executor (arena + plan + one graph capture of 40 launches + first-use forward)
+    takes ~0.35 s (measured: profiles/r04_exec_create.txt), a node holds ngpus x depth of them, RCCL's communicators ~1 s per device,
+    torch + library start-up ~20 s, filling depth x ngpus input slots ~0.1 s each, the run itself < 5 s -- and a 3x margin on all of it"""
+    return int(3 * (20 + 0.35 * ngpus * depth + 1.0 * ngpus + 0.1 * ngpus * depth + 5)) + 30
+
+
 def node_line(args, ngpus):
     """`bench.py --node` in a child process (its own HIP context on all devices; a hang or crash there costs only this entry)."""
     env = {k: v for k, v in os.environ.items()
            if not (k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "GROUP_WORLD_SIZE",
                          "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") or k.startswith("TORCHELASTIC") or k.startswith("TORCH_NCCL"))}
     # (at least 400 steps whatever --steps is: with 8 steps in flight a 20-step run would be mostly fill and drain)
+    node_depth = 8 if ngpus == 1 else 4                         # executors: ngpus x depth (8 devices x 4 = 32 graph captures, 32 x 75 MB arenas)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--node", "--gpus", str(ngpus), "--steps", str(max(args.steps, 400)), "--warmup", str(max(args.warmup, 40)),
-           "--depth", "8" if ngpus == 1 else "4"]               # (a host that waits for every step's records needs a deeper pipeline than the
-                                                                #  enqueue-only loop above; N > 1: fewer executors to create inside the time limit)
+           "--depth", str(node_depth)]                         # (a host that waits for every step's records needs a deeper pipeline than the
+                                                                #  enqueue-only loop above; N > 1: four steps in flight per device = the torchrun job's four chains)
     if args.global_batch > 0:
         cmd += ["--global-batch", str(args.global_batch)] + (["--merge-steps", str(args.merge_steps)] if args.merge_steps > 0 else [])
     try:
         # (bounded: at N > 1 this is the RCCL branch of the node path, which no box of rounds 1-3 could run; it must never cost the main line)
-        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=180)
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=node_budget_s(ngpus, node_depth))
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not lines:
             return {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
         d = json.loads(lines[-1])
-        return {k: d[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "host", "config")}
+        return {k: d.get(k) for k in ("value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "scaling", "host", "config")}
     except Exception as e:                                      # noqa: BLE001 -- an extra: never costs the main line
         return {"error": repr(e)[:400]}
 
@@ -279,6 +364,9 @@ def run_node(args):
     net = capi.Net()
     nd = capi.Node(net, N, GL, exec_flags=capi.FFGPU.CONCURRENT if D >= 3 else 0, node_flags=capi.Node.DEPTH(D))
     nd.set_scale(640, 320)
+    rccl_ranks = nd.rccl_ranks()                                # communicators ncclCommInitAll really created (0 on one device)
+    if N > 1 and rccl_ranks != N:
+        raise SystemExit("--node --gpus %d: the node created %d RCCL communicators" % (N, rccl_ranks))
     # synthetic frames: the same global stream as the torchrun job (seed 1236, frame 0 = letterboxed test.bmp); every slot of
     # every device holds its own batch, resident in HBM before the timed region (D x 78.6 MB per device > the Infinity Cache)
     img = check = None
@@ -330,7 +418,7 @@ def run_node(args):
             max(abs(float(a[k]) - float(b[k])) for k in ("x1", "y1", "x2", "y2")) < 0.05 for a, b in zip(got, check)))
     out = {"metric": "frames/sec yolo-fastest-1.1 @320x320 batch-64 per GPU (full forward: conv stack + YOLO decode + NMS, boxes in host memory)"
                      if not strong else "frames/sec yolo-fastest-1.1 @320x320 global batch %d sharded over the GPUs (full forward + boxes in host memory)" % G,
-           "value": round(G * args.steps / dt, 1), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+           "value": round(G * args.steps / dt, 1), "unit": "frames/s", "n_gpus": N, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "host": "C node API: one process, one host thread, ffgpu_node_run (= ffgpu_node_submit / ffgpu_node_wait, depth steps in flight) over include/ffcnn_hip.h",
@@ -378,10 +466,24 @@ def main():
     ap.add_argument("--depth", type=int, default=8, help="--node: steps in flight (FFGPU_NODE_DEPTH; one executor per slot and device)")
     ap.add_argument("--no-node-line", action="store_true", help="skip the extra c_node_api measurement (a child `bench.py --node` run by rank 0 after the timed job)")
     args = ap.parse_args()
-    if args.node:
-        return run_node(args)
 
     import torch
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    how, why = launch_plan(args.gpus, os.environ, ndev, node=args.node)
+    if how == "refuse":
+        print("bench.py: %s" % why, file=sys.stderr)
+        raise SystemExit(2)
+    if how == "node":
+        args.node = True
+        return run_node(args)
+    if how == "torchrun":
+        # `python bench.py --gpus N` with no launcher: become the launcher -- the same command line the driver uses for N > 1
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        print("bench.py: --gpus %d without a launcher: re-exec as %s" % (args.gpus, " ".join(cmd[1:9])), file=sys.stderr)
+        sys.stderr.flush()
+        os.execv(sys.executable, cmd)
+
     import torch.distributed as dist
     from ffcnn_amd import capi
     from ffcnn_amd import dist as ffdist
@@ -389,16 +491,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    assert world == args.gpus, (world, args.gpus)               # launch_plan() refused everything else
     torch.cuda.set_device(local)
     capi.lib().ffgpu_set_device(local)
     if world > 1 or args.force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 0      # size of the communicator this job really created
 
     strong = args.global_batch > 0
     if strong:
@@ -417,14 +517,12 @@ def main():
     MS = 1
     if strong:
         MS = args.merge_steps if args.merge_steps > 0 else max(1, 128 // B)
-    Bx = MS * B                                                 # frames per launch
     # chain streams are PRIORITY streams: the runtime keeps a pool of (at most four) hardware queues per priority level, so the four
     # chains get queues of their own whatever other streams the process holds (torch's, RCCL's) -- at the default priority which chains
     # end up behind each other on one hardware queue depends on how many streams were created before them
     prios = [int(v) for v in os.environ.get("FFCNN_BENCH_STREAM_PRIORITY", "-1").split(",")]      # (a list: chain j takes prios[j % len])
     prio = prios[0]
     stream = torch.cuda.Stream(priority=prio)
-    roof = roof_pw = None
     net = capi.Net()
     # weights: rank 0's folded filter rows -> every GPU over RCCL (one-off, outside the timed region)
     wptr, wbytes = net.weights_dev()
@@ -435,189 +533,219 @@ def main():
         wt.copy_(wtmp)
         torch.cuda.synchronize()
         net.weights_commit()                 # refresh the packed LDS images derived from the filter rows
-    # One executor per chain.  Single GPU: the NMS kernel writes the records straight into a pinned host mirror
-    # (FFGPU_HOST_DETS), so the boxes are on the host when the step ends with no copy between two graph launches.
-    # Several GPUs: the library's NMS kernel also writes each forward's records into a slot of a device ring
-    # (ffgpu_exec_set_ring; nothing but graph launches sits on the compute stream); every --gather-every steps a side
-    # stream gathers the finished group over RCCL (one message per rank and group instead of one per step: xGMI
-    # collectives are latency-bound at this size) and moves the gathered block to rank 0's host while the next
-    # forwards already run.  The boxes of a step reach rank 0 at most one group later, and the last, partial group is
-    # flushed inside the timed region.
-    gather_mode = world > 1 or args.force_gather
-    host_dets = not gather_mode
-    # Batches are independent, so consecutive steps go to S executors on S streams in turn (each its own arena and graph,
-    # no events between them).  The chains run in lockstep (tools/ramp.py): S copies of every launch are on the device
-    # together and fill the SIMDs that one launch leaves idle.  The head branch inside a chain is off.
-    S = max(1, args.streams)
-    M = args.gather_every
-    if M <= 0:                                                  # groups a short run can fill at least once
-        M = 64
-        while M > S and 2 * M > max(-(-args.steps // MS), 2 * S):
-            M //= 2
-    M = max(M, (S + 1) // 2)
-    if gather_mode and (2 * M) % S:
-        raise SystemExit("--gather-every * 2 must be a multiple of --streams")
-    os.environ.setdefault("FFGPU_BRANCH", "0" if S > 1 else "1")
-    flags = (capi.FFGPU.HOST_DETS if host_dets else 0) | (capi.FFGPU.SPLIT2 if args.split else 0)
-    if S >= 3:
-        flags |= capi.FFGPU.CONCURRENT      # plan for throughput: several chains fill the device together
-    exs = [net.executor(Bx, flags) for _ in range(S)]
-    streams = [stream] + [torch.cuda.Stream(priority=prios[j % len(prios)]) for j in range(1, S)]
-    ex = exs[0]
-    model_bytes, model_flops = ex.work_model()
 
-    # synthetic frames: the GLOBAL batch is seeded once (every rank draws the same stream and keeps its shard, so the strong-
-    # scaling job processes the same 256 frames whatever N is); frame 0 of the job is the letterboxed test.bmp
-    check = None
-    K_in = max(1, args.input_sets)
-    xs = []
-    g = torch.Generator(device="cuda").manual_seed(1236)
-    img = None
-    if rank == 0:
-        # frame 0 = data/test.bmp through the library's own net_input; expected boxes are the
-        # reference's (tests/golden/boxes.json, produced by the unmodified reference build)
-        try:
-            bgr, w, h = capi.load_bmp(os.path.join(ROOT, "data", "test.bmp"))
-            net.set_input_image(bgr, w, h)
-            img = torch.from_numpy(net.input.copy()).cuda()
-            check = json.load(open(os.path.join(ROOT, "tests", "golden", "boxes.json")))["net_320x320_v0"]["boxes"]
-        except Exception as e:
-            print("bench: golden check unavailable: %r" % (e,), file=sys.stderr)
-    # the steps take K distinct batches in turn (frame 0 is the test image in each of them, the rest differs): one batch used
-    # over and over would sit in the 256 MB Infinity Cache and the first layer would never read HBM
-    for k in range(K_in):
-        xk = torch.empty((Bx, 3, 320, 320), device="cuda")      # the shards of MS consecutive steps behind each other
-        for q in range(MS):
-            for c0 in range(0, G, 64):                          # one global batch in chunks; keep what falls into [lo, lo + B)
-                cn = min(64, G - c0)
-                chunk = torch.rand((cn, 3, 320, 320), device="cuda", generator=g)
-                a, b = max(c0, lo), min(c0 + cn, lo + B)
-                if a < b:
-                    xk[q * B + a - lo:q * B + b - lo] = chunk[a - c0:b - c0]
-                del chunk
-        if img is not None:
-            xk[0] = img
-        xs.append(xk)
-    x = xs[0]
-    for e in exs:
-        e.set_scale(640, 320)   # every frame is treated as a 640-wide source letterboxed to 320 (test.bmp's ratio)
+    def job(MS, with_roofline):
+        """executors, inputs, rings, warm-up and the timed steps for MS steps per launch; returns what the report needs"""
+        roof = roof_pw = None
+        Bx = MS * B                                             # frames per launch
+        # One executor per chain.  Single GPU: the NMS kernel writes the records straight into a pinned host mirror
+        # (FFGPU_HOST_DETS), so the boxes are on the host when the step ends with no copy between two graph launches.
+        # Several GPUs: the library's NMS kernel also writes each forward's records into a slot of a device ring
+        # (ffgpu_exec_set_ring; nothing but graph launches sits on the compute stream); every --gather-every steps a side
+        # stream gathers the finished group over RCCL (one message per rank and group instead of one per step: xGMI
+        # collectives are latency-bound at this size) and moves the gathered block to rank 0's host while the next
+        # forwards already run.  The boxes of a step reach rank 0 at most one group later, and the last, partial group is
+        # flushed inside the timed region.
+        gather_mode = world > 1 or args.force_gather
+        host_dets = not gather_mode
+        # Batches are independent, so consecutive steps go to S executors on S streams in turn (each its own arena and graph,
+        # no events between them).  The chains run in lockstep (tools/ramp.py): S copies of every launch are on the device
+        # together and fill the SIMDs that one launch leaves idle (DESIGN.md section 4).  The head branch inside a chain is off.
+        S = max(1, args.streams)
+        M = args.gather_every
+        if M <= 0:                                                  # groups a short run can fill at least once
+            M = 64
+            while M > S and 2 * M > max(-(-args.steps // MS), 2 * S):
+                M //= 2
+        M = max(M, (S + 1) // 2)
+        if gather_mode and (2 * M) % S:
+            raise SystemExit("--gather-every * 2 must be a multiple of --streams")
+        os.environ.setdefault("FFGPU_BRANCH", "0" if S > 1 else "1")
+        flags = (capi.FFGPU.HOST_DETS if host_dets else 0) | (capi.FFGPU.SPLIT2 if args.split else 0)
+        if S >= 3:
+            flags |= capi.FFGPU.CONCURRENT      # plan for throughput: several chains fill the device together
+        exs = [net.executor(Bx, flags) for _ in range(S)]
+        streams = [stream] + [torch.cuda.Stream(priority=prios[j % len(prios)]) for j in range(1, S)]
+        ex = exs[0]
+        model_bytes, model_flops = ex.work_model()
 
-    dptr, dbytes = ex.dets_dev()
-    # ring of two groups of M slots: the library's NMS kernel writes forward k's records into slot k % 2M itself
-    # (ffgpu_exec_set_ring), so nothing but graph launches sits on the compute stream
-    ring = torch.empty((2, M, dbytes), dtype=torch.uint8, device="cuda") if gather_mode else None
-    # what travels is the COMPACT form of a step's records (ffgpu_pack_records on the side stream: 25 KB instead of 198 KB
-    # per step at batch 64 -- the fixed-size records are almost all unused box slots), room for 16 boxes per frame on average
-    CAP = 16 * Bx
-    pbytes = capi.packed_records_bytes(Bx, CAP)
-    cring = torch.empty((2, M, pbytes), dtype=torch.uint8, device="cuda") if gather_mode else None
-    big = torch.empty((world, M * pbytes), dtype=torch.uint8, device="cuda") if (gather_mode and rank == 0) else None
-    glist = list(big.unbind(0)) if big is not None else None
-    host = [torch.empty((world, M * pbytes), dtype=torch.uint8).pin_memory() for _ in range(2)] if (gather_mode and rank == 0) else None
-    comm = torch.cuda.Stream() if gather_mode else None
-    ev_comm = [torch.cuda.Event() for _ in range(2)]
-    shipped = {"group": -1, "slot": 0}                          # where the newest step's records sit on rank 0's host
+        # synthetic frames: the GLOBAL batch is seeded once (every rank draws the same stream and keeps its shard, so the strong-
+        # scaling job processes the same 256 frames whatever N is); frame 0 of the job is the letterboxed test.bmp
+        check = None
+        K_in = max(1, args.input_sets)
+        xs = []
+        g = torch.Generator(device="cuda").manual_seed(1236)
+        img = None
+        if rank == 0:
+            # frame 0 = data/test.bmp through the library's own net_input; expected boxes are the
+            # reference's (tests/golden/boxes.json, produced by the unmodified reference build)
+            try:
+                bgr, w, h = capi.load_bmp(os.path.join(ROOT, "data", "test.bmp"))
+                net.set_input_image(bgr, w, h)
+                img = torch.from_numpy(net.input.copy()).cuda()
+                check = json.load(open(os.path.join(ROOT, "tests", "golden", "boxes.json")))["net_320x320_v0"]["boxes"]
+            except Exception as e:
+                print("bench: golden check unavailable: %r" % (e,), file=sys.stderr)
+        # the steps take K distinct batches in turn (frame 0 is the test image in each of them, the rest differs): one batch used
+        # over and over would sit in the 256 MB Infinity Cache and the first layer would never read HBM
+        for k in range(K_in):
+            xk = torch.empty((Bx, 3, 320, 320), device="cuda")      # the shards of MS consecutive steps behind each other
+            for q in range(MS):
+                for c0 in range(0, G, 64):                          # one global batch in chunks; keep what falls into [lo, lo + B)
+                    cn = min(64, G - c0)
+                    chunk = torch.rand((cn, 3, 320, 320), device="cuda", generator=g)
+                    a, b = max(c0, lo), min(c0 + cn, lo + B)
+                    if a < b:
+                        xk[q * B + a - lo:q * B + b - lo] = chunk[a - c0:b - c0]
+                    del chunk
+            if img is not None:
+                xk[0] = img
+            xs.append(xk)
+        x = xs[0]
+        for e in exs:
+            e.set_scale(640, 320)   # every frame is treated as a 640-wide source letterboxed to 320 (test.bmp's ratio)
 
-    ev_fwd = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
+        dptr, dbytes = ex.dets_dev()
+        # ring of two groups of M slots: the library's NMS kernel writes forward k's records into slot k % 2M itself
+        # (ffgpu_exec_set_ring), so nothing but graph launches sits on the compute stream
+        ring = torch.empty((2, M, dbytes), dtype=torch.uint8, device="cuda") if gather_mode else None
+        # what travels is the COMPACT form of a step's records (ffgpu_pack_records on the side stream: 25 KB instead of 198 KB
+        # per step at batch 64 -- the fixed-size records are almost all unused box slots), room for 16 boxes per frame on average
+        CAP = 16 * Bx
+        pbytes = capi.packed_records_bytes(Bx, CAP)
+        cring = torch.empty((2, M, pbytes), dtype=torch.uint8, device="cuda") if gather_mode else None
+        big = torch.empty((world, M * pbytes), dtype=torch.uint8, device="cuda") if (gather_mode and rank == 0) else None
+        glist = list(big.unbind(0)) if big is not None else None
+        host = [torch.empty((world, M * pbytes), dtype=torch.uint8).pin_memory() for _ in range(2)] if (gather_mode and rank == 0) else None
+        comm = torch.cuda.Stream() if gather_mode else None
+        ev_comm = [torch.cuda.Event() for _ in range(2)]
+        shipped = {"group": -1, "slot": 0}                          # where the newest step's records sit on rank 0's host
 
-    def ship(g, nslots=None):                                   # side stream: gather group g of the ring, D2H on rank 0
-        ns = M if nslots is None else nslots                   # a flushed, partial group moves only the slots that were written
-        nb = ns * pbytes
-        for j in range(S):
-            ev_fwd[g][j].record(streams[j])
-        with torch.cuda.stream(comm):
+        ev_fwd = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
+
+        def ship(g, nslots=None):                                   # side stream: gather group g of the ring, D2H on rank 0
+            ns = M if nslots is None else nslots                   # a flushed, partial group moves only the slots that were written
+            nb = ns * pbytes
             for j in range(S):
-                comm.wait_event(ev_fwd[g][j])                   # every chain has written its slots of the group
-            capi.pack_records_dev(ring[g].data_ptr(), ns, Bx, Bx, CAP, cring[g].data_ptr(), comm.cuda_stream)
-            ffdist.gather_records(dist, cring[g].view(-1)[:nb], dst=0, out=[t[:nb] for t in glist] if glist is not None else None)
-            if rank == 0:
-                host[g][:, :nb].copy_(big[:, :nb], non_blocking=True)   # one D2H copy for the whole job's records of the group
-            ev_comm[g].record(comm)
+                ev_fwd[g][j].record(streams[j])
+            with torch.cuda.stream(comm):
+                for j in range(S):
+                    comm.wait_event(ev_fwd[g][j])                   # every chain has written its slots of the group
+                capi.pack_records_dev(ring[g].data_ptr(), ns, Bx, Bx, CAP, cring[g].data_ptr(), comm.cuda_stream)
+                ffdist.gather_records(dist, cring[g].view(-1)[:nb], dst=0, out=[t[:nb] for t in glist] if glist is not None else None)
+                if rank == 0:
+                    host[g][:, :nb].copy_(big[:, :nb], non_blocking=True)   # one D2H copy for the whole job's records of the group
+                ev_comm[g].record(comm)
 
-    def step(i):
-        j = i % S                                               # executor / stream of this step
-        if not gather_mode:                                     # in-order streams: no events, no copies
+        def step(i):
+            j = i % S                                               # executor / stream of this step
+            if not gather_mode:                                     # in-order streams: no events, no copies
+                exs[j].forward_dev(xs[i % K_in].data_ptr(), streams[j].cuda_stream)
+                shipped["group"] = j
+                return
+            g, slot = ffdist.ring_slot(i, M)
+            if slot < S:
+                streams[j].wait_event(ev_comm[g])                   # this group's previous gather has read it
             exs[j].forward_dev(xs[i % K_in].data_ptr(), streams[j].cuda_stream)
-            shipped["group"] = j
-            return
-        g, slot = ffdist.ring_slot(i, M)
-        if slot < S:
-            streams[j].wait_event(ev_comm[g])                   # this group's previous gather has read it
-        exs[j].forward_dev(xs[i % K_in].data_ptr(), streams[j].cuda_stream)
-        shipped["group"], shipped["slot"] = g, slot
-        if ffdist.group_due(i, M):
-            ship(g)
+            shipped["group"], shipped["slot"] = g, slot
+            if ffdist.group_due(i, M):
+                ship(g)
 
-    def flush(n_done):                                          # a partial last group still has to travel
-        if gather_mode and n_done % M != 0:
-            ship(ffdist.ring_slot(n_done, M)[0], n_done % M)
+        def flush(n_done):                                          # a partial last group still has to travel
+            if gather_mode and n_done % M != 0:
+                ship(ffdist.ring_slot(n_done, M)[0], n_done % M)
 
-    def restart():                                              # forwards are counted from 0 again (slot 0 of group 0)
-        if gather_mode:
+        def restart():                                              # forwards are counted from 0 again (slot 0 of group 0)
+            if gather_mode:
+                torch.cuda.synchronize()
+                for j, e in enumerate(exs):                         # executor j's forward k is global step k * S + j
+                    e.set_ring(ring.data_ptr() + j * dbytes, 2 * M // S, S * Bx)
+
+        def fence():
             torch.cuda.synchronize()
-            for j, e in enumerate(exs):                         # executor j's forward k is global step k * S + j
-                e.set_ring(ring.data_ptr() + j * dbytes, 2 * M // S, S * Bx)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
 
-    def fence():
+        # One HIP graph per executor, captured on its first forward and valid for every input buffer (the input pointer travels
+        # through the executor's device parameter block): every (executor, input set) pair runs once here anyway, so nothing of
+        # a first use -- graph capture, page mapping of a fresh buffer -- can land inside the timed region
+        untimed = 0                                                 # forwards (launches of the whole net) enqueued before t0, reported in the line
+        for k in range(max(K_in, S)):
+            for j in range(S):
+                exs[j].forward_dev(xs[k % K_in].data_ptr(), streams[j].cuda_stream)
+                untimed += 1
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # One HIP graph per executor, captured on its first forward and valid for every input buffer (the input pointer travels
-    # through the executor's device parameter block): every (executor, input set) pair runs once here anyway, so nothing of
-    # a first use -- graph capture, page mapping of a fresh buffer -- can land inside the timed region
-    untimed = 0                                                 # forwards (launches of the whole net) enqueued before t0, reported in the line
-    for k in range(max(K_in, S)):
-        for j in range(S):
-            exs[j].forward_dev(xs[k % K_in].data_ptr(), streams[j].cuda_stream)
-            untimed += 1
-    torch.cuda.synchronize()
-    assert all(e.graph_captures == 1 for e in exs)
-    if gather_mode:                                             # ... and RCCL sets its communicator up on the first collective
+        assert all(e.graph_captures == 1 for e in exs)
+        if gather_mode:                                             # ... and RCCL sets its communicator up on the first collective
+            restart()
+            with torch.cuda.stream(comm):
+                ffdist.gather_records(dist, cring[0].view(-1), dst=0, out=glist)
+            torch.cuda.synchronize()
+        # The single-kernel rooflines (BASELINE config[1] / config[2]) are measured HERE, between set-up and the net's warm-up:
+        # (a) after the executors exist -- the 3.4 GB + 0.3 GB these measurements allocate and free, taken first, left the
+        # library's arenas on worse-placed memory (the same net then ran 15 % slower); (b) before the timed net -- the device
+        # comes out of them in its sustained clock / memory state.  After idle it needs ~10 ms of work to get there
+        # (tools/short_run.py: 20 steps straight after a 50 ms pause run at 153 k frames/s, the same 20 steps back to back at
+        # 182 k), which a 5-step warm-up (1.8 ms) does not provide; both measurements are independent of the net's.
+        if world == 1 and not args.no_kernel_roofline and with_roofline:
+            roof = kernel_roofline(torch, capi, stream)
+            roof_pw = pw_roofline(torch, capi, stream)
+            torch.cuda.synchronize()
+        else:
+            # N > 1 (or --no-kernel-roofline): the same device state by other means -- ~40 ms of untimed forwards in front of the
+            # W warm-up steps, on every rank.  Without them a short run at N > 1 is measured on a device that is still ramping
+            # while the N = 1 run (which has just done its roofline launches) is not: 173 k against 184 k frames/s per GPU at 20
+            # steps, a 6 % "scaling loss" that is measurement order and nothing else.
+            for i in range(max(S, 128 // MS // S * S)):
+                exs[i % S].forward_dev(xs[i % K_in].data_ptr(), streams[i % S].cuda_stream)
+                untimed += 1
+            torch.cuda.synchronize()
+        # warm-up and timed steps are numbered from 0 each, so both start on a fresh group and end with a flush
+        nl_warm, nl = -(-args.warmup // MS), -(-args.steps // MS)    # launches (a launch = MS steps; a ragged last one still does MS)
         restart()
-        with torch.cuda.stream(comm):
-            ffdist.gather_records(dist, cring[0].view(-1), dst=0, out=glist)
-        torch.cuda.synchronize()
-    # The single-kernel rooflines (BASELINE config[1] / config[2]) are measured HERE, between set-up and the net's warm-up:
-    # (a) after the executors exist -- the 3.4 GB + 0.3 GB these measurements allocate and free, taken first, left the
-    # library's arenas on worse-placed memory (the same net then ran 15 % slower); (b) before the timed net -- the device
-    # comes out of them in its sustained clock / memory state.  After idle it needs ~10 ms of work to get there
-    # (tools/short_run.py: 20 steps straight after a 50 ms pause run at 153 k frames/s, the same 20 steps back to back at
-    # 182 k), which a 5-step warm-up (1.8 ms) does not provide; both measurements are independent of the net's.
-    if world == 1 and not args.no_kernel_roofline:
-        roof = kernel_roofline(torch, capi, stream)
-        roof_pw = pw_roofline(torch, capi, stream)
-        torch.cuda.synchronize()
-    else:
-        # N > 1 (or --no-kernel-roofline): the same device state by other means -- ~40 ms of untimed forwards in front of the
-        # W warm-up steps, on every rank.  Without them a short run at N > 1 is measured on a device that is still ramping
-        # while the N = 1 run (which has just done its roofline launches) is not: 173 k against 184 k frames/s per GPU at 20
-        # steps, a 6 % "scaling loss" that is measurement order and nothing else.
-        for i in range(max(S, 128 // MS // S * S)):
-            exs[i % S].forward_dev(xs[i % K_in].data_ptr(), streams[i % S].cuda_stream)
-            untimed += 1
-        torch.cuda.synchronize()
-    # warm-up and timed steps are numbered from 0 each, so both start on a fresh group and end with a flush
-    nl_warm, nl = -(-args.warmup // MS), -(-args.steps // MS)    # launches (a launch = MS steps; a ragged last one still does MS)
-    restart()
-    for i in range(nl_warm):
-        step(i)
-    untimed += nl_warm
-    flush(nl_warm)
-    fence()
-    restart()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(nl):
-        step(i)
-    flush(nl)
-    fence()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        for i in range(nl_warm):
+            step(i)
+        untimed += nl_warm
+        flush(nl_warm)
+        fence()
+        restart()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(nl):
+            step(i)
+        flush(nl)
+        fence()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        return dict(exs=exs, streams=streams, xs=xs, x=x, ex=ex, model_bytes=model_bytes, model_flops=model_flops, dt=dt, untimed=untimed, shipped=shipped, host=host, pbytes=pbytes, roof=roof, roof_pw=roof_pw, check=check, K_in=K_in, S=S, M=M, Bx=Bx, flags=flags, host_dets=host_dets, gather_mode=gather_mode)
+
+    J = job(MS, True)
+    exs = J["exs"]
+    streams = J["streams"]
+    xs = J["xs"]
+    x = J["x"]
+    ex = J["ex"]
+    model_bytes = J["model_bytes"]
+    model_flops = J["model_flops"]
+    dt = J["dt"]
+    untimed = J["untimed"]
+    shipped = J["shipped"]
+    host = J["host"]
+    pbytes = J["pbytes"]
+    roof = J["roof"]
+    roof_pw = J["roof_pw"]
+    check = J["check"]
+    K_in = J["K_in"]
+    S = J["S"]
+    M = J["M"]
+    Bx = J["Bx"]
+    flags = J["flags"]
+    host_dets = J["host_dets"]
+    gather_mode = J["gather_mode"]
 
     out = None
     if rank == 0:
@@ -639,7 +767,7 @@ def main():
             "metric": "frames/sec yolo-fastest-1.1 @320x320 batch-64 per GPU (full forward: conv stack + YOLO decode + NMS, boxes on rank 0)"
                       if not strong else
                       "frames/sec yolo-fastest-1.1 @320x320 global batch %d sharded over the GPUs (full forward + boxes on rank 0)" % G,
-            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[3])" if not strong else
@@ -723,13 +851,30 @@ def main():
         out["gpu_vs_cpu_1thread"] = round(fps / out["cpu_baseline"]["value"], 1) if out["cpu_baseline"]["value"] else None
     for e in exs:
         e.close()
+    exs = []
+    if strong and MS > 1:
+        # the same job with ONE step per launch (--merge-steps 1): what "batch 256 over N GPUs" gives when every launch carries exactly its
+        # shard of one step.  Every rank takes part (the gather is collective); reported beside the merged headline, never instead of it.
+        del xs, x
+        J = None
+        torch.cuda.empty_cache()
+        J1 = job(1, False)
+        if out is not None:
+            out["strong_unmerged"] = {"value": round(G * args.steps / J1["dt"], 1), "unit": "frames/s", "ms_per_step": round(J1["dt"] / args.steps * 1e3, 4),
+                                      "steps_per_launch": 1, "frames_per_launch": J1["Bx"],
+                                      "what": "same job, --merge-steps 1: every launch carries this GPU's shard of ONE %d-frame step" % G}
+            out["config"]["steps_per_launch_note"] = ("value = %d consecutive steps' shards per launch (~128 frames per launch at every N, so the launch size does "
+                                                      "not shrink with N); strong_unmerged = one step per launch" % MS)
+        for e in J1["exs"]:
+            e.close()
+        xs = x = J1 = None
     net.close()
     if world > 1 or args.force_gather:
         dist.destroy_process_group()
     if out is not None and not args.no_node_line:
         # north_star's host path -- plain C over the C-ABI, one process for all GPUs -- measured beside the torchrun job: rank 0
         # (alone by now: the process group is gone, the other ranks are leaving) runs `bench.py --node` on the same N devices
-        del xs, x
+        xs = x = J = None
         torch.cuda.empty_cache()
         out["c_node_api"] = node_line(args, world)
     if out is not None:

@@ -65,7 +65,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_read_boxes", "ffgpu_exec_cand_capacity", "ffgpu_exec_graph_captures",
            "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_dwpw_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records", "ffgpu_unpack_records",
            "ffgpu_shard_range", "ffgpu_node_create", "ffgpu_node_destroy", "ffgpu_node_ndev", "ffgpu_node_shard", "ffgpu_node_set_scale",
-           "ffgpu_node_input_dev", "ffgpu_node_input_slot_dev", "ffgpu_node_depth", "ffgpu_node_forward", "ffgpu_node_forward_host",
+           "ffgpu_node_input_dev", "ffgpu_node_input_slot_dev", "ffgpu_node_depth", "ffgpu_node_rccl_ranks", "ffgpu_node_forward", "ffgpu_node_forward_host",
            "ffgpu_node_submit", "ffgpu_node_wait", "ffgpu_node_run"]
 # include/ffcnn_hip_diag.h (libffcnn_hip_diag.so: lab equipment, its own library)
 DIAG_EXPORTS = ["ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_pipe_probe2"]
@@ -160,6 +160,8 @@ def lib():
     L.ffgpu_node_input_slot_dev.restype = vp
     L.ffgpu_node_input_slot_dev.argtypes = [vp, i, i]
     L.ffgpu_node_depth.argtypes = [vp]
+    if hasattr(L, "ffgpu_node_rccl_ranks"):                     # (absent from older tuning builds loaded through FFCNN_HIP_LIB)
+        L.ffgpu_node_rccl_ranks.argtypes = [vp]
     L.ffgpu_node_submit.restype = C.c_long
     L.ffgpu_node_submit.argtypes = [vp, f32p]
     L.ffgpu_node_wait.argtypes = [vp, C.c_long, vp]
@@ -465,22 +467,21 @@ class Node:
         t = lib().ffgpu_node_submit(self.h, frames.ctypes.data_as(f32p) if frames is not None else None)
         if t < 0:
             raise RuntimeError("ffgpu_node_submit failed: %s" % last_error())
-        if frames is not None:
-            self._held[t] = frames                              # the upload is asynchronous: the host frames live until wait(t)
-        return t
+        return t                                                # (numpy memory is staged inside submit: `frames` is free again)
 
     def wait(self, ticket):
         out = np.zeros(self.total, DETS_DTYPE)
         _check(lib().ffgpu_node_wait(self.h, ticket, out.ctypes.data), "ffgpu_node_wait")
-        self._held.pop(ticket, None)
         return out
 
     def wait_into(self, ticket, out):
         """as wait(), into a caller-owned DETS_DTYPE array of `total` records"""
         assert out.dtype == DETS_DTYPE and len(out) == self.total and out.flags["C_CONTIGUOUS"]
         _check(lib().ffgpu_node_wait(self.h, ticket, out.ctypes.data), "ffgpu_node_wait")
-        self._held.pop(ticket, None)
         return out
+
+    def rccl_ranks(self):
+        return lib().ffgpu_node_rccl_ranks(self.h)
 
     def run(self, steps, out=None):
         """ffgpu_node_run: `steps` pipelined steps from the slots' input buffers (the loop runs in C); records of the last step"""
@@ -495,7 +496,6 @@ class Node:
 
     def __init__(self, net, ndev, global_batch, devices=None, exec_flags=0, node_flags=0):
         self.net, self.ndev, self.total = net, ndev, global_batch
-        self._held = {}
         dv = (C.c_int * ndev)(*devices) if devices is not None else None
         self.h = lib().ffgpu_node_create(net.p, ndev, dv, global_batch, exec_flags, node_flags)
         if not self.h:

@@ -35,6 +35,7 @@ struct ConvDesc {
     int   res_act;        // activation applied after adding the residual
     int   flags;          // FFGPU_COMPAT_V6
     long  in_cs, in_ns, out_cs, out_ns, res_cs, res_ns;
+    int   nsplit;         // implicit-GEMM split-K factor frozen at plan time (ffgpu_conv_plan_split); 0 = decided at launch (single-layer calls)
 };
 
 static inline int conv_k4(const ConvDesc &d) { return (d.fs * d.fs * (d.ic / d.groups) + 3) & ~3; }
@@ -63,6 +64,7 @@ int    ffgpu_dwpw_pack(const ConvDesc &dw, const ConvDesc &pw, float *pk, hipStr
 int    ffgpu_launch_dwpw(const ConvDesc &dw, const ConvDesc &pw, const float *wpack, hipStream_t s);
 
 size_t ffgpu_pw_pack_floats(const ConvDesc &d);
+int    ffgpu_conv_plan_split(const ConvDesc &d);       // the split-K factor k_conv_igemm would pick for this layer NOW (environment read once, here)
 int    ffgpu_pw_pack(const ConvDesc &d, float *pk, hipStream_t s);
 
 // Per-executor parameter block in device memory: what changes from one forward to the next without changing the

@@ -81,13 +81,22 @@ bool pinned_ours(const void *ptr, size_t bytes)
 }
 
 constexpr size_t BOUNCE_BYTES = (size_t)16 << 20;
-std::mutex g_bounce_mu;
-char *g_bounce = nullptr;            // allocated on first use, kept for the life of the process (portable: every device may DMA from it)
+// one staging buffer (and lock) per DEVICE, allocated on first use and kept for the life of the process: readers / writers of
+// different GPUs (the node path, one thread per device in a caller) do not queue behind each other
+struct Bounce { std::mutex mu; char *p = nullptr; };
+Bounce g_bounces[32];
 
-int bounce_ready()
+Bounce &bounce_cur()
 {
-    if (g_bounce) return 0;
-    FFGPU_CHECK(hipHostMalloc((void **)&g_bounce, BOUNCE_BYTES, hipHostMallocPortable));
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return g_bounces[(unsigned)dev % 32u];
+}
+
+int bounce_ready(Bounce &b)          // (call with b.mu held)
+{
+    if (b.p) return 0;
+    FFGPU_CHECK(hipHostMalloc((void **)&b.p, BOUNCE_BYTES, hipHostMallocPortable));
     return 0;
 }
 }
@@ -97,8 +106,10 @@ static int copy_h2d(void *d_dst, const void *h_src, size_t bytes)
 {
     if (bytes == 0) return 0;
     if (pinned_ours(h_src, bytes)) { FFGPU_CHECK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); return 0; }
-    std::lock_guard<std::mutex> lk(g_bounce_mu);
-    if (bounce_ready()) return -1;
+    Bounce &bn = bounce_cur();
+    std::lock_guard<std::mutex> lk(bn.mu);
+    if (bounce_ready(bn)) return -1;
+    char *const g_bounce = bn.p;
     for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
         const size_t n = std::min(BOUNCE_BYTES, bytes - off);
         memcpy(g_bounce, static_cast<const char *>(h_src) + off, n);
@@ -111,8 +122,10 @@ static int copy_d2h(void *h_dst, const void *d_src, size_t bytes)
 {
     if (bytes == 0) return 0;
     if (pinned_ours(h_dst, bytes)) { FFGPU_CHECK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost)); return 0; }
-    std::lock_guard<std::mutex> lk(g_bounce_mu);
-    if (bounce_ready()) return -1;
+    Bounce &bn = bounce_cur();
+    std::lock_guard<std::mutex> lk(bn.mu);
+    if (bounce_ready(bn)) return -1;
+    char *const g_bounce = bn.p;
     for (size_t off = 0; off < bytes; off += BOUNCE_BYTES) {
         const size_t n = std::min(BOUNCE_BYTES, bytes - off);
         FFGPU_CHECK(hipMemcpy(g_bounce, static_cast<const char *>(d_src) + off, n, hipMemcpyDeviceToHost));
@@ -580,7 +593,7 @@ static int plan(ffgpu_exec *ex)
         size_t tot = 0;
         for (Step &st : S) {
             if (st.kind == S_IRB) tot += ffgpu_irb_pack_floats(st.irb);
-            if (st.kind == S_CONV) tot += ffgpu_pw_pack_floats(st.conv);
+            if (st.kind == S_CONV) { st.conv.nsplit = ffgpu_conv_plan_split(st.conv); tot += ffgpu_pw_pack_floats(st.conv); }    // (split-K frozen with the plan)
             if (st.kind == S_DWPW) tot += ffgpu_dwpw_pack_floats(st.conv, st.conv2);
         }
         if (tot) {
@@ -1122,7 +1135,7 @@ extern "C" int ffgpu_exec_forward_bgr_dev(ffgpu_exec *ex, const unsigned char *d
     else                           { sh = H; sw = (int)((long)sh * w / h); s1 = h; s2 = sh; }
     ex->s1 = s1; ex->s2 = s2;
     const bool no_u8_front = getenv("FFGPU_NO_U8_FRONT") != nullptr;             // (tuning / tests: always the two-kernel path)
-    if (w == W && h == H && (reinterpret_cast<uintptr_t>(d_bgr) & 7) == 0 && !no_u8_front && front_reads_u8(ex)) {
+    if (w == W && h == H && (reinterpret_cast<uintptr_t>(d_bgr) & 3) == 0 && !no_u8_front && front_reads_u8(ex)) {
         // no resize (net_input copies pixel for pixel): the first kernel converts the bytes itself -- no fp32 batch in between
         const int pitch = (w * 3 + 3) & ~3;
         ex->bgr = d_bgr; ex->bgr_pitch = pitch; ex->bgr_frame = (long)pitch * h;
@@ -1244,9 +1257,15 @@ extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float
     const float *src = tensor_ptr(ex, ex->canon[layer]) + (size_t)frame * plane;
     {   // the frame's planes (one per channel, N planes apart in CNHW) gathered into the bounce buffer, then into caller memory
         const size_t row = plane * sizeof(float), per = std::max<size_t>(1, BOUNCE_BYTES / row);
-        if (row > BOUNCE_BYTES) { ffgpu_set_error("read_layer: a plane of %zu bytes exceeds the staging buffer", row); return -1; }
-        std::lock_guard<std::mutex> lk(g_bounce_mu);
-        if (bounce_ready()) return -1;
+        if (row > BOUNCE_BYTES) {                                  // a plane larger than the staging buffer (> 2048 x 2048 floats): contiguous, chunked plane by plane
+            for (size_t c = 0; c < (size_t)o.c; c++)
+                if (copy_d2h(host_out + c * plane, src + c * plane * ex->N, row)) return -1;
+            return (int)(plane * o.c);
+        }
+        Bounce &bn = bounce_cur();
+        std::lock_guard<std::mutex> lk(bn.mu);
+        if (bounce_ready(bn)) return -1;
+        char *const g_bounce = bn.p;
         for (size_t c0 = 0; c0 < (size_t)o.c; c0 += per) {
             const size_t nc = std::min(per, (size_t)o.c - c0);
             FFGPU_CHECK(hipMemcpy2D(g_bounce, row, src + c0 * plane * ex->N, row * ex->N, row, nc, hipMemcpyDeviceToHost));

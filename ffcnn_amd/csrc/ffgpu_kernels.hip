@@ -21,6 +21,16 @@
 
 #define WAVE 64
 
+// A pointer READ FROM MEMORY (the executor's parameter block, ConvDesc::in_ind) is a generic ("flat") pointer to the compiler:
+// its loads become flat_load_*, which count on lgkmcnt as well as vmcnt, and SIInsertWaitcnts then turns every wait for an LDS
+// read into lgkmcnt(0) while one is in flight -- a kernel that prefetches input rows from HBM under arithmetic fed by LDS
+// tables (k_front, k_conv_igemm) waited a full memory latency at its first table read.  The input tensor IS global memory, so
+// say so: loads through a gfp are global_load_* (vmcnt only).
+#define FFG __attribute__((address_space(1)))
+typedef const FFG float *gfp;
+__device__ __forceinline__ gfp to_global(const float *p) { return (gfp)p; }
+template <class T> __device__ __forceinline__ T gld(gfp p) { return *(const FFG T *)p; }
+
 __device__ __forceinline__ float act_apply(float x, int act)
 {
     switch (act) {
@@ -42,7 +52,7 @@ __global__ void k_conv_generic(ConvDesc d)
     const int gic = d.ic / d.groups, goc = d.oc / d.groups;
     const int k4 = (d.fs * d.fs * gic + 3) & ~3, rl = k4 + 4;
     const bool v6dw5 = (d.flags & FFGPU_COMPAT_V6) && d.pad == 2 && d.fs == 5 && d.stride == 1 && gic == 1;
-    const float *in0 = d.in_ind ? *d.in_ind : d.in;                  // executor parameter block (one graph for every input buffer)
+    const gfp in0 = to_global(d.in_ind ? *d.in_ind : d.in);          // executor parameter block (one graph for every input buffer)
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int x = (int)(idx % d.ow);
         long t = idx / d.ow;
@@ -51,10 +61,10 @@ __global__ void k_conv_generic(ConvDesc d)
         const int o = (int)(t / d.N);
         const int g = o / goc;
         const float *w = d.filt + (long)o * rl;
-        const float *src = in0 + (long)g * gic * d.in_cs + (long)n * d.in_ns;
+        const gfp src = in0 + (long)g * gic * d.in_cs + (long)n * d.in_ns;
         float acc = 0.f;
         for (int ci = 0; ci < gic; ci++) {
-            const float *pl = src + (long)ci * d.in_cs;
+            const gfp pl = src + (long)ci * d.in_cs;
             for (int ky = 0; ky < d.fs; ky++) {
                 if (v6dw5 && d.oh > 2 && y == d.oh - 2 && ky == 0) continue;   // conv-v6.c:422-441
                 const int sy = y * d.stride - d.pad + ky;

@@ -178,6 +178,8 @@ int         ffgpu_node_ndev(const ffgpu_node *node);
 int         ffgpu_node_shard(const ffgpu_node *node, int rank, int *lo, int *hi, int *device);
 int         ffgpu_node_set_scale(ffgpu_node *node, int s1, int s2);       /* as ffgpu_exec_set_scale, every rank */
 int         ffgpu_node_depth(const ffgpu_node *node);
+/* communicators ncclCommInitAll created for this node: ndev on the RCCL path, 0 with one device or FFGPU_NODE_LOOPBACK */
+int         ffgpu_node_rccl_ranks(const ffgpu_node *node);
 /* rank's input shard on ITS device, (hi - lo) x C x H x W fp32 frame-major, owned by the node (the buffer the NEXT
  * submitted step reads; ffgpu_node_input_slot_dev names a slot explicitly): fill it there ... */
 float      *ffgpu_node_input_dev(ffgpu_node *node, int rank);
@@ -189,11 +191,14 @@ int         ffgpu_node_forward_host(ffgpu_node *node, const float *h_frames, ffg
 /* Pipelined form: submit enqueues the next step on every device (h_frames may be NULL: the slot's input buffers are used as
  * they are) plus its gather and returns the step's ticket (>= 0) without waiting; wait(ticket) blocks until that step's
  * records are on the host and copies them.  At most `depth` tickets may be outstanding.  h_frames is copied into the slot's
- * page-locked staging buffer before submit returns: the caller's buffer is free again at once. */
+ * page-locked staging buffer before submit returns: the caller's buffer is free again at once -- with ONE exception: frames that
+ * lie inside memory from ffgpu_host_alloc (page-locked memory this library owns) are uploaded straight from there by an
+ * asynchronous DMA and must stay untouched until ffgpu_node_wait(ticket) has returned. */
 long        ffgpu_node_submit(ffgpu_node *node, const float *h_frames);
 int         ffgpu_node_wait(ffgpu_node *node, long ticket, ffgpu_frame_dets *host_out);
 /* The loop above as one call: `steps` steps from the slots' input buffers, `depth` of them in flight (collect step i - depth,
- * submit step i), every step's records brought to the host; host_out (may be NULL) receives the last step's. */
+ * submit step i), every step's records brought to the host; host_out (may be NULL) receives the last step's.  If a step fails the
+ * steps still in flight are drained (their records dropped) before the error is returned: the node stays usable. */
 int         ffgpu_node_run(ffgpu_node *node, long steps, ffgpu_frame_dets *host_out);
 
 /* ---- single operators on device tensors (CNHW, any batch) --------------- */

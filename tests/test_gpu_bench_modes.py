@@ -71,3 +71,31 @@ def test_bench_strong_scaling_job():
     d = run([sys.executable, "bench.py", "--force-gather", "--global-batch", "256"] + COMMON + NO_NODE, port=29543)
     check_line(d, "strong", 256)
     assert d["config"]["frames_per_gpu"] == 256
+
+
+@pytest.mark.gpu
+def test_bench_refuses_more_gpus_than_visible():
+    """`bench.py --gpus N` uses N GPUs however it is launched, or fails loudly: on a box with fewer devices the plain command, the
+    --node form and a torchrun job whose world size differs from --gpus all exit non-zero and print no JSON line."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    for cmd in ([sys.executable, "bench.py", "--gpus", str(n)] + COMMON,
+                [sys.executable, "bench.py", "--node", "--gpus", str(n), "--steps", "4", "--warmup", "2"]):
+        r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0, r.stdout[-500:]
+        assert "HIP device" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stderr[-500:]
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8"] + COMMON, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr, r.stderr[-500:]
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_reports_both_schedules():
+    """strong scaling with a shard of 32 frames (the per-GPU load of 256 frames over 8 GPUs): the headline merges 4 steps per launch,
+    the one-step-per-launch figure stands beside it; the line names the size of the RCCL communicator it created"""
+    d = run([sys.executable, "bench.py", "--force-gather", "--global-batch", "32"] + COMMON + NO_NODE, port=29549)
+    check_line(d, "strong", 32)
+    assert d["config"]["steps_per_launch"] == 4 and d["config"]["frames_per_launch"] == 128
+    u = d["strong_unmerged"]
+    assert u["steps_per_launch"] == 1 and u["frames_per_launch"] == 32 and u["value"] > 0
+    assert d["rccl_ranks"] == 1                                  # --force-gather: a one-rank communicator really exists

@@ -1,0 +1,20 @@
+#!/bin/bash
+# A/B of library builds on ONE box, alternating runs (box-to-box spread is larger than most kernel changes):
+#   tools/ab_bench.sh <rounds> <steps> libA.so libB.so ...      (paths relative to ffcnn_amd/lib/)
+# prints frames/s of every run and the per-library median; env for a run can be attached as "lib.so:VAR=1,VAR2=3"
+cd "$(dirname "$0")/.." || exit 1
+rounds=$1; steps=$2; shift 2
+declare -A vals
+for ((r = 0; r < rounds; r++)); do
+  for spec in "$@"; do
+    lib=${spec%%:*}; envs=""
+    [[ "$spec" == *:* ]] && envs=${spec#*:}
+    v=$(env ${envs//,/ } FFCNN_HIP_LIB=$PWD/ffcnn_amd/lib/$lib python bench.py --steps $steps --warmup 40 --no-cpu-baseline --no-kernel-roofline --no-extras --no-node-line 2>/dev/null |
+        python -c 'import sys, json; d = json.loads([l for l in sys.stdin if l.startswith("{")][-1]); print(d["value"], d["config"]["boxes_match_reference_golden_frame0"])')
+    echo "round $r  $spec  $v"
+    vals[$spec]+="${v%% *} "
+  done
+done
+for spec in "$@"; do
+  python -c 'import sys, statistics as st; v = [float(x) for x in sys.argv[2:]]; print("%-60s median %.0f  min %.0f  max %.0f frames/s (%d runs)" % (sys.argv[1], st.median(v), min(v), max(v), len(v)))' "$spec" ${vals[$spec]}
+done
