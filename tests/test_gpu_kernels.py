@@ -186,6 +186,35 @@ def test_pw_gemm(env, orc, shape, wm, monkeypatch):
         check(got.reshape(oc, N, H, W)[:, 0], o, "pw_gemm %s frame 0 vs oracle" % (shape,))
 
 
+# ragged K (72, 100, 120: partial k-steps of 32), ragged channel blocks (255, 130, 21), one pixel tile and many, residual-free; sigmoid
+@pytest.mark.parametrize("shape", [(256, 512, 2, 20, 20, 2), (120, 120, 3, 20, 20, 2), (120, 255, 2, 20, 20, 0), (192, 96, 4, 10, 10, 2), (96, 255, 2, 10, 10, 0),
+                                   (64, 130, 3, 10, 10, 2), (100, 200, 1, 12, 12, 1), (72, 300, 21, 20, 20, 2), (33, 21, 1, 6, 6, 3), (8, 16, 2, 4, 4, 2)])
+@pytest.mark.parametrize("mt", [0, 1, 2])
+def test_pw_x3(env, orc, shape, mt, monkeypatch):
+    """pointwise layer as SPLIT-bf16 products on the bf16 matrix cores (ffgpu_pw_x3.inc: three exact bf16 parts per operand, six partial
+    products, fp32 accumulation): same tolerance as every fp32 kernel against generic and the oracle, and -- the claim of the kernel --
+    as close to the oracle as the fp32 MFMA kernel is (a summation order, not a precision): |d| <= 2^-20 * scale' * sum|w x| + 1 ulp"""
+    capi, torch = env
+    if mt:
+        monkeypatch.setenv("FFGPU_PWX3_MT", str(mt))
+    ic, oc, N, H, W, act = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f = make_filter(rng, oc, ic)
+    assert capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc, capi.FFGPU.K_PW_X3) == "pw_x3"
+    got = run_dev(capi, torch, x, f, N, W, H, ic, 1, 0, 1, 1, oc, act, capi.FFGPU.K_PW_X3)
+    ref = run_dev(capi, torch, x, f, N, W, H, ic, 1, 0, 1, 1, oc, act, capi.FFGPU.K_GENERIC)
+    check(got, ref, "pw_x3 %s vs generic" % (shape,))
+    xf = x.reshape(ic, N, H, W)
+    o = orc.groupconv(np.ascontiguousarray(xf[:, 0]), f, 1, 0, 1, 1, act)
+    g0 = got.reshape(oc, N, H, W)[:, 0]
+    check(g0, o, "pw_x3 %s frame 0 vs oracle" % (shape,))
+    if act != 3:
+        k4 = (ic + 3) & ~3
+        bound = 2.0 ** -20 * np.abs(f[:, k4])[:, None, None] * np.einsum("ok,khw->ohw", np.abs(f[:, :ic]).astype(np.float64), np.abs(xf[:, 0]).astype(np.float64))
+        assert np.all(np.abs(g0 - o) <= bound + 2.0 ** -22 * np.abs(o) + 1e-30), float(np.max(np.abs(g0 - o) / (bound + 1e-30)))
+
+
 IGEMM_SHAPES = [  # (ic, oc, N, H, W, fs, stride, pad, act)
     (16, 32, 2, 24, 20, 3, 1, 1, 2), (32, 64, 1, 13, 13, 3, 1, 1, 2), (64, 130, 3, 7, 9, 3, 1, 1, 0), (8, 21, 2, 12, 8, 5, 1, 2, 0),
     (24, 48, 2, 17, 15, 3, 2, 1, 2), (12, 8, 1, 11, 11, 5, 2, 1, 1), (20, 10, 2, 9, 9, 3, 1, 0, 1), (128, 256, 1, 6, 4, 3, 1, 1, 2),
