@@ -5,8 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the whole hot path (first conv ... YOLO decode + NMS)
-over one batch of 64 synthetic 320x320x3 frames PER GPU, inputs resident in HBM,
+One "step" = one pass of the whole hot path (net_input's conversion ... first conv ...
+YOLO decode + NMS) over one batch of 64 synthetic 320x320 u8 BGR frames PER GPU
+(`--input f32`: frames already converted to planar fp32, the
+headline of rounds 1-3, reported beside the value either way), inputs resident in HBM,
 ending with the NMS'd boxes of every frame of the job in host memory on rank 0
 (RCCL gather of the fixed-size per-frame detection records for N > 1).  Weak
 scaling by default: the global batch is 64*N.  `--global-batch 256` is BASELINE
@@ -423,7 +425,7 @@ def run_node(args):
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "host": "C node API: one process, one host thread, ffgpu_node_run (= ffgpu_node_submit / ffgpu_node_wait, depth steps in flight) over include/ffcnn_hip.h",
            "config": {"workload": "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[%d])" % (4 if strong else 3),
-                      "frames_per_gpu": G // N, "global_batch": G, "parallelism": "dp%d" % N, "steps_in_flight": D * MS,
+                      "input": "f32", "frames_per_gpu": G // N, "global_batch": G, "parallelism": "dp%d" % N, "steps_in_flight": D * MS,
                       "steps_per_launch": MS, "frames_per_launch": GL // N,
                       "exchange": "none (one device: the NMS kernel writes the records into pinned host memory)" if N == 1 else
                                   "ncclBroadcast of the weights at create; per step one grouped ncclSend/ncclRecv of the packed records per peer + one D2H",
@@ -464,6 +466,10 @@ def main():
                     help="the C host path: ONE process drives all --gpus devices through ffgpu_node_create / submit / wait (RCCL broadcast of "
                          "the weights, packed gather of the records); not under torchrun")
     ap.add_argument("--depth", type=int, default=8, help="--node: steps in flight (FFGPU_NODE_DEPTH; one executor per slot and device)")
+    ap.add_argument("--input", choices=["u8", "f32"], default=os.environ.get("FFCNN_BENCH_INPUT", "u8"),
+                    help="what a step starts from, resident in HBM: u8 = 64 u8 BGR 320x320 images per GPU (SURVEY 8(d) row 4; the first kernel converts "
+                         "them with net_input's arithmetic, ffcnn.c:259-289) -- the default since round 4; f32 = frames already converted to planar "
+                         "fp32 (rounds 1-3's headline; reported beside the value either way)")
     ap.add_argument("--no-node-line", action="store_true", help="skip the extra c_node_api measurement (a child `bench.py --node` run by rank 0 after the timed job)")
     args = ap.parse_args()
 
@@ -588,19 +594,35 @@ def main():
                 print("bench: golden check unavailable: %r" % (e,), file=sys.stderr)
         # the steps take K distinct batches in turn (frame 0 is the test image in each of them, the rest differs): one batch used
         # over and over would sit in the 256 MB Infinity Cache and the first layer would never read HBM
+        u8 = args.input == "u8"
+        img8 = None
+        if img is not None:                                         # the same frame as u8 BGR: byte = round(255 x) (net_input computed x = byte * (1 / 255))
+            img8 = torch.round(img * 255.0).clamp(0, 255).to(torch.uint8).flip(0).permute(1, 2, 0).reshape(320, 960).contiguous()
         for k in range(K_in):
-            xk = torch.empty((Bx, 3, 320, 320), device="cuda")      # the shards of MS consecutive steps behind each other
+            if u8:
+                xk = torch.empty((Bx, 320, 960), dtype=torch.uint8, device="cuda")     # frame-major u8 BGR, pitch 960
+            else:
+                xk = torch.empty((Bx, 3, 320, 320), device="cuda")  # the shards of MS consecutive steps behind each other
             for q in range(MS):
                 for c0 in range(0, G, 64):                          # one global batch in chunks; keep what falls into [lo, lo + B)
                     cn = min(64, G - c0)
-                    chunk = torch.rand((cn, 3, 320, 320), device="cuda", generator=g)
+                    if u8:
+                        chunk = torch.randint(0, 256, (cn, 320, 960), dtype=torch.uint8, device="cuda", generator=g)
+                    else:
+                        chunk = torch.rand((cn, 3, 320, 320), device="cuda", generator=g)
                     a, b = max(c0, lo), min(c0 + cn, lo + B)
                     if a < b:
                         xk[q * B + a - lo:q * B + b - lo] = chunk[a - c0:b - c0]
                     del chunk
             if img is not None:
-                xk[0] = img
+                xk[0] = img8 if u8 else img
             xs.append(xk)
+
+        def fwd(e, xk, st):                                         # one step of executor e from resident frames xk on stream st
+            if xk.dtype == torch.uint8:
+                e.forward_bgr_dev(xk.data_ptr(), 320, 320, stream=st.cuda_stream)
+            else:
+                e.forward_dev(xk.data_ptr(), st.cuda_stream)
         x = xs[0]
         for e in exs:
             e.set_scale(640, 320)   # every frame is treated as a 640-wide source letterboxed to 320 (test.bmp's ratio)
@@ -640,13 +662,13 @@ def main():
         def step(i):
             j = i % S                                               # executor / stream of this step
             if not gather_mode:                                     # in-order streams: no events, no copies
-                exs[j].forward_dev(xs[i % K_in].data_ptr(), streams[j].cuda_stream)
+                fwd(exs[j], xs[i % K_in], streams[j])
                 shipped["group"] = j
                 return
             g, slot = ffdist.ring_slot(i, M)
             if slot < S:
                 streams[j].wait_event(ev_comm[g])                   # this group's previous gather has read it
-            exs[j].forward_dev(xs[i % K_in].data_ptr(), streams[j].cuda_stream)
+            fwd(exs[j], xs[i % K_in], streams[j])
             shipped["group"], shipped["slot"] = g, slot
             if ffdist.group_due(i, M):
                 ship(g)
@@ -673,10 +695,11 @@ def main():
         untimed = 0                                                 # forwards (launches of the whole net) enqueued before t0, reported in the line
         for k in range(max(K_in, S)):
             for j in range(S):
-                exs[j].forward_dev(xs[k % K_in].data_ptr(), streams[j].cuda_stream)
+                fwd(exs[j], xs[k % K_in], streams[j])
                 untimed += 1
         torch.cuda.synchronize()
-        assert all(e.graph_captures == 1 for e in exs)
+        caps0 = [e.graph_captures for e in exs]                     # one graph per executor (+ one for the u8 form of the first kernel): nothing is captured after this point
+        assert all(c <= 2 for c in caps0), caps0
         if gather_mode:                                             # ... and RCCL sets its communicator up on the first collective
             restart()
             with torch.cuda.stream(comm):
@@ -698,7 +721,7 @@ def main():
             # while the N = 1 run (which has just done its roofline launches) is not: 173 k against 184 k frames/s per GPU at 20
             # steps, a 6 % "scaling loss" that is measurement order and nothing else.
             for i in range(max(S, 128 // MS // S * S)):
-                exs[i % S].forward_dev(xs[i % K_in].data_ptr(), streams[i % S].cuda_stream)
+                fwd(exs[i % S], xs[i % K_in], streams[i % S])
                 untimed += 1
             torch.cuda.synchronize()
         # warm-up and timed steps are numbered from 0 each, so both start on a fresh group and end with a flush
@@ -721,10 +744,12 @@ def main():
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        return dict(exs=exs, streams=streams, xs=xs, x=x, ex=ex, model_bytes=model_bytes, model_flops=model_flops, dt=dt, untimed=untimed, shipped=shipped, host=host, pbytes=pbytes, roof=roof, roof_pw=roof_pw, check=check, K_in=K_in, S=S, M=M, Bx=Bx, flags=flags, host_dets=host_dets, gather_mode=gather_mode)
+        assert [e.graph_captures for e in exs] == caps0, "a graph was captured inside the timed region"
+        return dict(fwd=fwd, exs=exs, streams=streams, xs=xs, x=x, ex=ex, model_bytes=model_bytes, model_flops=model_flops, dt=dt, untimed=untimed, shipped=shipped, host=host, pbytes=pbytes, roof=roof, roof_pw=roof_pw, check=check, K_in=K_in, S=S, M=M, Bx=Bx, flags=flags, host_dets=host_dets, gather_mode=gather_mode)
 
     J = job(MS, True)
     exs = J["exs"]
+    fwd = J["fwd"]
     streams = J["streams"]
     xs = J["xs"]
     x = J["x"]
@@ -759,19 +784,29 @@ def main():
                 blk = host[shipped["group"]][0].numpy()[shipped["slot"] * pbytes:(shipped["slot"] + 1) * pbytes]
                 rec = ffdist.unpack_records(blk, capi.DETS_DTYPE)
             got = rec[0]["box"][: rec[0]["count"]]
+            # u8 input: the library scales the boxes as net_input does for the image it is given (ffcnn.c:267-273: a 320x320 image -> factor 1);
+            # the golden boxes are in the pixels of the 640-wide source the frame was letterboxed from (factor 640 / 320)
+            bs = 2.0 if args.input == "u8" else 1.0
             ok = bool(len(got) == len(check) and all(
                 int(a["type"]) == int(b["type"]) and abs(float(a["score"]) - float(b["score"])) < 1e-4 and
-                max(abs(float(a[k]) - float(b[k])) for k in ("x1", "y1", "x2", "y2")) < 0.05 for a, b in zip(got, check)))
+                max(abs(bs * float(a[k]) - float(b[k])) for k in ("x1", "y1", "x2", "y2")) < 0.05 for a, b in zip(got, check)))
         per_gpu_s = dt / args.steps                             # seconds per step; every GPU handles B frames of it
+        u8 = args.input == "u8"
+        in_what = "u8 BGR frames -> net_input's conversion in the first kernel -> " if u8 else ""
+        in_cfg = ("320x320 u8 BGR frames resident in HBM (SURVEY 8(d) row 4), converted by the first kernel with net_input's arithmetic (ffcnn.c:259-289)" if u8 else
+                  "320x320x3 fp32 frames resident in HBM")
+        if u8:                                                  # the first kernel reads 3 bytes per pixel instead of 12
+            model_bytes = model_bytes - 9.0 * 320 * 320 * Bx
         out = {
-            "metric": "frames/sec yolo-fastest-1.1 @320x320 batch-64 per GPU (full forward: conv stack + YOLO decode + NMS, boxes on rank 0)"
+            "metric": ("frames/sec yolo-fastest-1.1 @320x320 batch-64 per GPU (%sfull forward: conv stack + YOLO decode + NMS, boxes on rank 0)" % in_what)
                       if not strong else
-                      "frames/sec yolo-fastest-1.1 @320x320 global batch %d sharded over the GPUs (full forward + boxes on rank 0)" % G,
+                      "frames/sec yolo-fastest-1.1 @320x320 global batch %d sharded over the GPUs (%sfull forward + boxes on rank 0)" % (G, in_what),
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM (BASELINE config[3])" if not strong else
-                                    "yolo-fastest-1.1.cfg full net, 320x320x3 fp32 frames resident in HBM, global batch %d in contiguous shards (BASELINE config[4])" % G),
+            "config": {"workload": ("yolo-fastest-1.1.cfg full net, %s (BASELINE config[3])" % in_cfg if not strong else
+                                    "yolo-fastest-1.1.cfg full net, %s, global batch %d in contiguous shards (BASELINE config[4])" % (in_cfg, G)),
+                       "input": args.input,
                        "frames_per_gpu": B, "global_batch": G, "parallelism": "dp%d" % world,
                        "steps_per_launch": MS, "frames_per_launch": Bx,
                        "input_sets": K_in,
@@ -780,7 +815,7 @@ def main():
                                                              "set-up and the warm-up steps" if roof is not None else "none besides the forwards"),
                        "launches_per_step": ex.kernel_count, "arena_MB": round(ex.arena_bytes / 2**20, 1),
                        "executors": S, "pipelining": "%d executors on %d streams take the batches in turn%s" % (S, S, ", each split in two half-batch chains" if args.split else ""), "gather": ("RCCL gather of %d steps' records (packed: %d bytes per step and rank) + D2H on a side stream, overlapped with the next steps" % (M, pbytes)) if gather_mode else "records written to pinned host memory by the NMS kernel",
-                       "graph_captures_per_executor": max(e.graph_captures for e in exs),
+                       "graph_captures_per_executor": max(e.graph_captures for e in exs),     # (one per input format used: the u8 form of the first kernel has its own graph)
                        "weights": "data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL, untimed)",
                        "boxes_match_reference_golden_frame0": ok},
             # the whole net against the two ceilings that exist for it (per GPU): what the FUSED launch list must move
@@ -802,26 +837,33 @@ def main():
         torch.cuda.synchronize()
         nlat = 30
         for i in range(5):
-            exs[0].forward_dev(xs[i % K_in].data_ptr(), streams[0].cuda_stream)
+            fwd(exs[0], xs[i % K_in], streams[0])
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(nlat):
-            exs[0].forward_dev(xs[i % K_in].data_ptr(), streams[0].cuda_stream)
+            fwd(exs[0], xs[i % K_in], streams[0])
         torch.cuda.synchronize()
         out["roofline_net"]["single_chain_ms_per_batch"] = round((time.perf_counter() - t1) / nlat / MS * 1e3, 4)
+        # the same job from the OTHER input format (rounds 1-3 reported fp32-resident frames; since round 4 the value starts from the u8
+        # images SURVEY 8(d) row 4 names): same executors, same chains, its own length so that it does not depend on --steps
         gu = torch.Generator(device="cuda").manual_seed(1236)
-        us = [torch.randint(0, 256, (Bx, 320, 960), dtype=torch.uint8, device="cuda", generator=gu) for _ in range(K_in)]
-        n8 = 200 // S * S                                       # (its own length: an extra of a 20-step run is not a 20-step measurement)
+        if args.input == "u8":
+            other = [torch.rand((Bx, 3, 320, 320), device="cuda", generator=gu) for _ in range(K_in)]
+        else:
+            other = [torch.randint(0, 256, (Bx, 320, 960), dtype=torch.uint8, device="cuda", generator=gu) for _ in range(K_in)]
+        n8 = 200 // S * S
         for rep in range(2):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for i in range(n8):
-                exs[i % S].forward_bgr_dev(us[i % K_in].data_ptr(), 320, 320, stream=streams[i % S].cuda_stream)
+                fwd(exs[i % S], other[i % K_in], streams[i % S])
             torch.cuda.synchronize()
             t8 = time.perf_counter() - t1
-        out["config"]["u8_bgr_input"] = {"value": round(Bx * n8 / t8, 1), "unit": "frames/s", "steps": n8,
-                                         "what": "same job, %d u8 BGR 320x320 frames per step resident in HBM -> ffgpu_exec_forward_bgr_dev (images of the net's size: converted by the first kernel itself)" % B}
-        del us
+        out["config"]["fp32_resident_input" if args.input == "u8" else "u8_bgr_input"] = {
+            "value": round(Bx * n8 / t8, 1), "unit": "frames/s", "steps": n8,
+            "what": ("same job from %d frames per step already converted to planar fp32 (78.6 MB per 64 frames instead of 19.7 MB; the headline of rounds 1-3)" % B) if args.input == "u8" else
+                    ("same job, %d u8 BGR 320x320 frames per step resident in HBM -> ffgpu_exec_forward_bgr_dev (converted by the first kernel itself)" % B)}
+        del other
         # ... and the same frames with TWO consecutive steps per launch (what the strong-scaling mode does with its shards): not the
         # reported value -- BASELINE's config is a 64-frame batch per step and launch --, the headroom a serving loop has if it may
         # put two batches into one launch
@@ -835,7 +877,7 @@ def main():
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for i in range(n2):
-                    ex2[i % S].forward_dev(x2[i % len(x2)].data_ptr(), streams[i % S].cuda_stream)
+                    fwd(ex2[i % S], x2[i % len(x2)], streams[i % S])
                 torch.cuda.synchronize()
                 t2 = time.perf_counter() - t1
             out["config"]["two_steps_per_launch"] = {"value": round(2 * Bx * n2 / t2, 1), "unit": "frames/s", "launches": n2,

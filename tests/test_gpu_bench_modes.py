@@ -30,7 +30,7 @@ def check_line(d, scaling, frames):
     assert d["scaling"] == scaling and d["dtype"] == "f32" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["config"]["global_batch"] == frames
     assert d["config"]["boxes_match_reference_golden_frame0"] is True
-    assert d["config"]["graph_captures_per_executor"] == 1
+    assert d["config"]["graph_captures_per_executor"] <= 2       # the executor's graph + the u8 form's; bench.py itself asserts that none is captured after the warm-up
     assert abs(d["value"] - frames * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-3
 
 
