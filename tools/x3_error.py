@@ -22,7 +22,7 @@ for shape in SHAPES:
     t = [torch.from_numpy(a).cuda() for a in (x, f1, fd, f2, res)]
     outs, us = {}, {}
     for x3 in ("0", "1"):
-        os.environ["FFGPU_IRBW_X3"] = "7" if x3 == "1" else "0"
+        os.environ["FFGPU_IRBW_X3"] = "15" if x3 == "1" else "0"
         out = torch.full((oc * N, OH, OW), float("nan"), device="cuda")
         capi.irb_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr() if use_res else None, out.data_ptr(), N, W, H, ic, ec, oc, stride)
         us[x3] = capi.irb_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr() if use_res else None, out.data_ptr(), N, W, H, ic, ec, oc, stride, warmup=5, iters=50)
