@@ -246,6 +246,14 @@ def pw_roofline(torch, capi, stream):
                                  warmup=4, iters=50, stream=stream.cuda_stream)
     flops = 2.0 * oc * ic * N * H * W
     tfs = flops / (us * 1e-6) / 1e12
+    # beside it: the fp32-MFMA kernel of rounds 2-3 on the same tensors (k_pw_gemm32: v_mfma_f32_32x32x2_f32, the kernel AUTO picked until round 4)
+    f32k = None
+    try:
+        us32 = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2,
+                                       variant=capi.FFGPU.K_PW_GEMM, warmup=4, iters=30, stream=stream.cuda_stream)
+        f32k = {"kernel": "pw_gemm", "us_per_launch": round(us32, 2), "achieved": round(flops / us32 / 1e6, 2), "unit": "TFLOP/s", "frac": round(flops / us32 / 1e6 / FP32_MFMA_PEAK_TF, 4)}
+    except RuntimeError:
+        pass
     # beside it (NOT the product default, never used by the net's timed steps): the opt-in bf16-input variant of the same layer
     # (FFGPU_BF16_PW; its own tolerance in tests/test_gpu_kernels.py::test_pw_bf16) -- on the bf16 matrix cores the layer is
     # HBM-bound: 315 MB of fp32 input + output per launch
@@ -259,8 +267,16 @@ def pw_roofline(torch, capi, stream):
               "note": "opt-in reduced precision (bf16 inputs, fp32 accumulation); tolerance 2^-7 scale' sum|w x| per output"}
     except RuntimeError:
         pass
-    return {"bf16_opt_in": bf, "bound": "mfma", "kernel": capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc), "achieved": round(tfs, 2),
+    kname = capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc)
+    note = None
+    if kname == "pw_x3":
+        note = ("fp32-equivalent results from split operands: every fp32 value = three exact bf16 parts, six partial products per multiply-add on "
+                "v_mfma_f32_16x16x32_bf16, fp32 accumulation (ffgpu_pw_x3.inc; error as an fp32 summation order, tests/test_gpu_kernels.py::test_pw_x3). "
+                "`frac` stays priced against the fp32 matrix peak the reference's arithmetic implies (the fp32 MFMAs run at the fp32 vector rate: 157.3 TFLOP/s); "
+                "against what this form could reach -- the bf16 dense peak / 6 products = 416.7 TFLOP/s -- it is `frac_of_bf16_peak_over_6`")
+    return {"bf16_opt_in": bf, "fp32_mfma_kernel": f32k, "bound": "mfma", "kernel": kname, "achieved": round(tfs, 2),
             "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tfs / FP32_MFMA_PEAK_TF, 4),
+            "frac_of_bf16_peak_over_6": round(tfs / (2500.0 / 6.0), 4) if kname == "pw_x3" else None, "note": note,
             "us_per_launch": round(us, 2), "dtype": "f32",
             "workload": "pw1x1 256->512 20x20 batch 256 fp32 (BASELINE config[2])"}
 
@@ -540,7 +556,7 @@ def main():
         torch.cuda.synchronize()
         net.weights_commit()                 # refresh the packed LDS images derived from the filter rows
 
-    def job(MS, with_roofline):
+    def job(MS, with_roofline, input_kind=None):
         """executors, inputs, rings, warm-up and the timed steps for MS steps per launch; returns what the report needs"""
         roof = roof_pw = None
         Bx = MS * B                                             # frames per launch
@@ -579,6 +595,8 @@ def main():
         # scaling job processes the same 256 frames whatever N is); frame 0 of the job is the letterboxed test.bmp
         check = None
         K_in = max(1, args.input_sets)
+        if (input_kind or args.input) == "u8":
+            K_in *= 4                                               # 19.7 MB per batch: 32 sets (630 MB, as much as 8 fp32 sets) do not fit the 256 MB Infinity Cache
         xs = []
         g = torch.Generator(device="cuda").manual_seed(1236)
         img = None
@@ -594,7 +612,7 @@ def main():
                 print("bench: golden check unavailable: %r" % (e,), file=sys.stderr)
         # the steps take K distinct batches in turn (frame 0 is the test image in each of them, the rest differs): one batch used
         # over and over would sit in the 256 MB Infinity Cache and the first layer would never read HBM
-        u8 = args.input == "u8"
+        u8 = (input_kind or args.input) == "u8"
         img8 = None
         if img is not None:                                         # the same frame as u8 BGR: byte = round(255 x) (net_input computed x = byte * (1 / 255))
             img8 = torch.round(img * 255.0).clamp(0, 255).to(torch.uint8).flip(0).permute(1, 2, 0).reshape(320, 960).contiguous()
@@ -844,26 +862,6 @@ def main():
             fwd(exs[0], xs[i % K_in], streams[0])
         torch.cuda.synchronize()
         out["roofline_net"]["single_chain_ms_per_batch"] = round((time.perf_counter() - t1) / nlat / MS * 1e3, 4)
-        # the same job from the OTHER input format (rounds 1-3 reported fp32-resident frames; since round 4 the value starts from the u8
-        # images SURVEY 8(d) row 4 names): same executors, same chains, its own length so that it does not depend on --steps
-        gu = torch.Generator(device="cuda").manual_seed(1236)
-        if args.input == "u8":
-            other = [torch.rand((Bx, 3, 320, 320), device="cuda", generator=gu) for _ in range(K_in)]
-        else:
-            other = [torch.randint(0, 256, (Bx, 320, 960), dtype=torch.uint8, device="cuda", generator=gu) for _ in range(K_in)]
-        n8 = 200 // S * S
-        for rep in range(2):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(n8):
-                fwd(exs[i % S], other[i % K_in], streams[i % S])
-            torch.cuda.synchronize()
-            t8 = time.perf_counter() - t1
-        out["config"]["fp32_resident_input" if args.input == "u8" else "u8_bgr_input"] = {
-            "value": round(Bx * n8 / t8, 1), "unit": "frames/s", "steps": n8,
-            "what": ("same job from %d frames per step already converted to planar fp32 (78.6 MB per 64 frames instead of 19.7 MB; the headline of rounds 1-3)" % B) if args.input == "u8" else
-                    ("same job, %d u8 BGR 320x320 frames per step resident in HBM -> ffgpu_exec_forward_bgr_dev (converted by the first kernel itself)" % B)}
-        del other
         # ... and the same frames with TWO consecutive steps per launch (what the strong-scaling mode does with its shards): not the
         # reported value -- BASELINE's config is a 64-frame batch per step and launch --, the headroom a serving loop has if it may
         # put two batches into one launch
@@ -885,6 +883,18 @@ def main():
             for e in ex2:
                 e.close()
             del x2
+    if rank == 0 and world == 1 and not gather_mode and not args.no_extras:
+        # SURVEY 8(f) rows 2 / 3 as throughput (untimed extras): another darknet cfg (yolov3-tiny-shaped, implicit-GEMM kernels) and the
+        # reference CLI's geometry, batch 16 per step on four chains (tools/other_nets.py)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import other_nets
+            for e in exs:
+                e.close()
+            exs = []
+            out["config"]["other_nets"] = other_nets.rows(torch, capi)
+        except Exception as e:                                  # noqa: BLE001 -- an extra
+            out["config"]["other_nets"] = {"error": repr(e)[:300]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         for e in exs:
             e.close()
@@ -894,11 +904,24 @@ def main():
     for e in exs:
         e.close()
     exs = []
+    if world == 1 and not gather_mode and not args.no_extras:
+        # the same job from the OTHER input format, measured exactly like the value (own executors and inputs, same warm-up, K timed steps):
+        # rounds 1-3 reported fp32-resident frames; since round 4 the value starts from the u8 images SURVEY 8(d) row 4 names
+        xs = x = J = None
+        torch.cuda.empty_cache()
+        okind = "f32" if args.input == "u8" else "u8"
+        J2 = job(MS, False, okind)
+        out["config"]["fp32_resident_input" if okind == "f32" else "u8_bgr_input"] = {
+            "value": round(G * args.steps / J2["dt"], 1), "unit": "frames/s", "steps": args.steps, "ms_per_step": round(J2["dt"] / args.steps * 1e3, 4),
+            "what": ("same job, frames already converted to planar fp32 resident in HBM (78.6 MB per 64 frames instead of 19.7 MB): the headline of rounds 1-3" if okind == "f32" else
+                     "same job from u8 BGR 320x320 frames resident in HBM -> ffgpu_exec_forward_bgr_dev (converted by the first kernel itself)")}
+        for e in J2["exs"]:
+            e.close()
+        J2 = None
     if strong and MS > 1:
         # the same job with ONE step per launch (--merge-steps 1): what "batch 256 over N GPUs" gives when every launch carries exactly its
         # shard of one step.  Every rank takes part (the gather is collective); reported beside the merged headline, never instead of it.
-        del xs, x
-        J = None
+        xs = x = J = None
         torch.cuda.empty_cache()
         J1 = job(1, False)
         if out is not None:

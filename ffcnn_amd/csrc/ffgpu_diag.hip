@@ -199,3 +199,16 @@ extern "C" float ffgpu_membench(void *d_dst, const void *d_src, size_t bytes, in
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return ms * 1000.f / iters;
 }
+
+// ---- the slot tables of the split-bf16 expand GEMM (ffgpu_x3_terms.h), readable from the host: tests/test_x3_tables.py checks that
+// every partial product (weight part i, input part j, channel pair) with i + j <= 2 occurs exactly once and nothing else does
+#include "ffgpu_x3_terms.h"
+extern "C" int ffgpu_diag_x3_term(int ks1, int m, int d, int out[3])
+{
+    if ((ks1 != 2 && ks1 != 4 && ks1 != 6 && ks1 != 12) || m < 0 || m >= irbw_x3_nm(ks1) || d < 0 || d > 3) return -1;
+    const IrbwX3Term t = irbw_x3_term(ks1, m, d);
+    out[0] = t.wp; out[1] = t.xp; out[2] = t.pair;
+    return irbw_x3_nm(ks1);
+}
+extern "C" int ffgpu_diag_xl_op(int m) { return irbw_xl_op(m); }
+

@@ -396,7 +396,7 @@ def test_pw_bf16(env, orc, shape):
         worst = max(worst, float(err.max()))
     assert worst > 1e-5, "bf16 variant returned fp32-exact results: it did not run"
     # AUTO never picks it unless the flag is passed
-    assert capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc) in ("pw_gemm", "pw_mfma")
+    assert capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc) in ("pw_gemm", "pw_mfma", "pw_x3")
 
 
 def test_unsupported_variant_fails_loudly(env):

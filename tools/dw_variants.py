@@ -28,4 +28,4 @@ for rnd in range(4):
         res[i].append(us)
 for i, v in enumerate(variants):
     r = sorted(res[i])
-    print("%-48s median %.1f us  (%.3f of 8 TB/s)  runs %s" % (v or "default (band 4, U 4)", r[len(r) // 2], nbytes / r[len(r) // 2] / 1e6 / 8000, ["%.1f" % u for u in res[i]]))
+    print("%-48s median %.1f us  (%.3f of 8 TB/s)  runs %s" % (v or "default (band 4, U 4)", r[len(r) // 2], nbytes / r[len(r) // 2] / 1e3 / 8000, ["%.1f" % u for u in res[i]]))

@@ -1,0 +1,28 @@
+#!/bin/bash
+# GPU box: the judged artefacts of a round-4 stage into gpurun_out/<tag>_* (copy the ones to keep into profiles/).
+#   tools/build_skip_lib.sh            (here, before: the DIAG build for the ablation table travels with the snapshot)
+#   gpurun --timeout 2400 -- 'bash tools/profile_round4.sh r04_x'
+# = tools/profile_round3.sh (bench line, the driver's 20-step command, rocprofv3 --kernel-trace --stats of it, launch order, per-launch
+# table, pointwise GEMM counters, igemm table, DW traffic from separate --pmc passes, ablation with four chains in flight)
+# + the issue budget of one forward of the plan the bench runs (FFGPU_CONCURRENT): instruction counts and matrix-pipe busy cycles per
+# kernel, counters only, one --pmc pass each
+# + round 4's tables: split-bf16 fused blocks against the fp32-MFMA form, k_pw_x3 against the fp32 pointwise kernels, DW variants.
+set -u
+TAG=${1:-r04}
+R=$GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+bash tools/profile_round3.sh $TAG
+FLAGS=$(python -c "import sys; sys.path.insert(0, '$R'); from ffcnn_amd import capi; print(capi.FFGPU.CONCURRENT | capi.FFGPU.HOST_DETS)")
+REPS=4
+: > gpurun_out/${TAG}_issue_budget.txt
+for CTRS in "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+    rm -rf gpurun_out/pmc_issue
+    ( cd /tmp && timeout 600 rocprofv3 --pmc $CTRS -d "$R/gpurun_out/pmc_issue" -o t -- python "$R/tools/run_graph.py" 64 $REPS $FLAGS > "$R/gpurun_out/pmc_issue.log" 2>&1 )
+    DB=$(find gpurun_out/pmc_issue -name "*_results.db" | head -1)
+    [ -n "$DB" ] && python tools/pmc_total.py "$DB" $REPS >> gpurun_out/${TAG}_issue_budget.txt
+done
+rm -rf gpurun_out/pmc_issue
+timeout 300 python tools/x3_error.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_x3_fused_blocks.txt
+timeout 300 python tools/pw_x3_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-420 > gpurun_out/${TAG}_pw_x3.txt
+timeout 300 python tools/dw_variants.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_dw_variants.txt
+head -3 gpurun_out/${TAG}_issue_budget.txt
