@@ -10,7 +10,11 @@ for ((r = 0; r < rounds; r++)); do
   for spec in "$@"; do
     lib=${spec%%:*}; envs=""
     [[ "$spec" == *:* ]] && envs=${spec#*:}
-    v=$(env ${envs//,/ } FFCNN_HIP_LIB=$PWD/ffcnn_amd/lib/$lib python bench.py --steps $steps --warmup 40 --no-cpu-baseline --no-kernel-roofline --no-extras --no-node-line $BENCH_ARGS 2>/dev/null |
+    bargs=$BENCH_ARGS; evars=""
+    for kv in ${envs//,/ }; do
+      if [[ "$kv" == BENCH_ARGS=* ]]; then bargs="$bargs ${kv#BENCH_ARGS=}"; else evars="$evars $kv"; fi
+    done
+    v=$(env $evars FFCNN_HIP_LIB=$PWD/ffcnn_amd/lib/$lib python bench.py --steps $steps --warmup 40 --no-cpu-baseline --no-kernel-roofline --no-extras --no-node-line $bargs 2>/dev/null |
         python -c 'import sys, json; d = json.loads([l for l in sys.stdin if l.startswith("{")][-1]); print(d["value"], d["config"]["boxes_match_reference_golden_frame0"])')
     echo "round $r  $spec  $v"
     vals[$spec]+="${v%% *} "
