@@ -20,7 +20,10 @@ def write_random_weights(capi, cfg, path, w, h, seed=7):
             if L.type != 0:                                     # LAYER_TYPE_CONV
                 continue
             K = L.fs * L.fs * (L.c // L.groups)
-            fp.write(rng.uniform(-0.2, 0.2, L.fn).astype("<f4").tobytes())
+            # (the linear layers feed the [yolo] heads: a bias of -6 keeps the objectness of random weights below the threshold -- with every
+            #  anchor a candidate, 2 500 per frame, the greedy O(n^2) suppression of one workgroup per frame takes 8 ms and hides the conv stack)
+            bias = rng.uniform(-0.2, 0.2, L.fn) if L.activation != 0 else np.full(L.fn, -6.0)
+            fp.write(bias.astype("<f4").tobytes())
             if L.batchnorm:
                 fp.write(rng.uniform(0.5, 1.5, L.fn).astype("<f4").tobytes())
                 fp.write(rng.uniform(-0.3, 0.3, L.fn).astype("<f4").tobytes())
