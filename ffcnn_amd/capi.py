@@ -17,7 +17,7 @@ f32p = C.POINTER(C.c_float)
 class FFGPU:
     MAX_DET = 128
     KEEP_ALL, COMPAT_V6, NO_GRAPH, NO_FUSE, HOST_DETS, SPLIT2, CONCURRENT, BF16_PW = 1, 2, 4, 8, 16, 32, 64, 128
-    K_AUTO, K_GENERIC, K_DW_STREAM, K_DW_LDS, K_PW_MFMA, K_PW_GEMM, _K6, K_DENSE_SMALL, K_IGEMM, K_PW_BF16, K_GROUP_THIN, K_PW_X3 = range(12)
+    K_AUTO, K_GENERIC, K_DW_STREAM, K_DW_LDS, K_PW_MFMA, K_PW_GEMM, _K6, K_DENSE_SMALL, K_IGEMM, K_PW_BF16, K_GROUP_THIN, K_PW_X3, K_CONV_X3 = range(13)
 
 
 class LAYER(C.Structure):            # include/ffcnn.h (120 bytes)

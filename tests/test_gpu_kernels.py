@@ -253,6 +253,59 @@ def test_conv_igemm(env, orc, shape, split, monkeypatch):
         check(got.reshape(oc, N, OH, OW)[:, n], o, "conv_igemm %s frame %d vs oracle" % (shape, n))
 
 
+CONV_X3_SHAPES = [s for s in IGEMM_SHAPES if s[5:8] == (3, 1, 1) and s[4] >= 4 and s[0] % 8 == 0] + [
+    # several pixel ranges x several channel tiles; a ragged width with many frames; 16 channels (half of every k-step is padding); one group only
+    (48, 72, 4, 40, 44, 3, 1, 1, 2), (96, 40, 9, 13, 13, 3, 1, 1, 2), (16, 16, 2, 64, 64, 3, 1, 1, 0), (8, 20, 1, 9, 12, 3, 1, 1, 1),
+    (40, 48, 2, 30, 7, 3, 1, 1, 2), (56, 17, 3, 6, 10, 3, 1, 1, 3), (24, 100, 1, 5, 12, 3, 1, 1, 0), (8, 130, 4, 4, 4, 3, 1, 1, 2), (72, 24, 2, 8, 9, 3, 1, 1, 2),
+]
+
+
+@pytest.mark.parametrize("mt,nw", [(0, 8), (4, 4), (2, 8), (1, 4)])
+@pytest.mark.parametrize("shape", CONV_X3_SHAPES)
+def test_conv_x3(env, orc, shape, mt, nw, monkeypatch):
+    """dense 3x3 / stride 1 / pad 1 as SPLIT-bf16 products on the bf16 matrix cores (ffgpu_conv_x3.inc): against the generic kernel and the
+    oracle with the tolerance of every fp32 kernel, and -- the claim of the kernel -- as close to the oracle as an fp32 reorder is:
+    |d| <= 2^-20 * scale' * sum|w x| + 1 ulp.  All channel-tile heights (MT) and both workgroup sizes; widths that are not multiples of 4."""
+    capi, torch = env
+    if mt:
+        monkeypatch.setenv("FFGPU_IGX3_MT", str(mt))
+    monkeypatch.setenv("FFGPU_IGX3_NW", str(nw))
+    ic, oc, N, H, W, fs, stride, pad, act = shape
+    K = 9 * ic
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f = make_filter(rng, oc, K)
+    f[:, :K] *= 3.0 / np.sqrt(K)
+    assert capi.kernel_name(N, W, H, ic, 1, 1, 1, 3, oc, capi.FFGPU.K_CONV_X3) == "conv_x3"
+    got = run_dev(capi, torch, x, f, N, W, H, ic, 1, 1, 1, 3, oc, act, capi.FFGPU.K_CONV_X3)
+    ref = run_dev(capi, torch, x, f, N, W, H, ic, 1, 1, 1, 3, oc, act, capi.FFGPU.K_GENERIC)
+    check(got, ref, "conv_x3 %s vs generic" % (shape,))
+    xf = x.reshape(ic, N, H, W)
+    k4 = (K + 3) & ~3
+    fa = np.abs(f)
+    fa[:, k4], fa[:, k4 + 1] = 1.0, 0.0
+    for n in range(N):
+        o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, 1, 1, 1, 3, act)
+        g = got.reshape(oc, N, H, W)[:, n]
+        check(g, o, "conv_x3 %s frame %d vs oracle" % (shape, n))
+        if act != 3 and n == 0:
+            sabs = orc.groupconv(np.ascontiguousarray(np.abs(xf[:, n])), fa, 1, 1, 1, 3, 0).astype(np.float64)
+            bound = 2.0 ** -20 * np.abs(f[:, k4])[:, None, None] * sabs
+            assert np.all(np.abs(g - o) <= bound + 2.0 ** -22 * np.abs(o) + 1e-30), float(np.max(np.abs(g - o) / (bound + 1e-30)))
+
+
+def test_conv_x3_auto_pick(env, monkeypatch):
+    """AUTO gives the big 3x3 layers of a darknet backbone to conv_x3, keeps k_conv_igemm (split-K) for launches that would not fill the chip,
+    and FFGPU_IG_X3=0 switches it off"""
+    capi, torch = env
+    assert capi.kernel_name(16, 104, 104, 32, 1, 1, 1, 3, 64) == "conv_x3"
+    assert capi.kernel_name(1, 13, 13, 256, 1, 1, 1, 3, 512) == "conv_igemm"
+    assert capi.kernel_name(16, 104, 104, 32, 1, 1, 2, 3, 64) == "conv_igemm"          # stride 2
+    assert capi.kernel_name(16, 104, 104, 36, 1, 1, 1, 3, 64) == "conv_igemm"          # input channels not in whole blocks of 8
+    monkeypatch.setenv("FFGPU_IG_X3", "0")
+    assert capi.kernel_name(16, 104, 104, 32, 1, 1, 1, 3, 64) == "conv_igemm"
+
+
 THIN_SHAPES = [  # (ic, oc, groups, N, H, W, fs, stride, pad, act): 2..7 input channels per group
     (8, 8, 4, 2, 9, 11, 3, 1, 1, 2), (12, 24, 4, 1, 13, 13, 3, 1, 1, 2), (64, 64, 16, 3, 20, 20, 3, 1, 1, 2), (28, 16, 4, 2, 7, 5, 5, 1, 2, 0),
     (6, 9, 3, 2, 17, 16, 3, 2, 1, 1), (10, 30, 2, 1, 8, 8, 1, 1, 0, 3), (21, 35, 7, 2, 6, 6, 3, 1, 0, 2), (4, 5, 1, 2, 10, 9, 2, 1, 0, 2),

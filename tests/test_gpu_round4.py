@@ -79,3 +79,75 @@ def test_pw_x3_back_to_back(env, shape, mt, monkeypatch):
         torch.cuda.synchronize()
         d = (y - ref).abs()
         assert not torch.isnan(y).any() and float(d.max()) <= 1e-4, "rep %d: %d outputs off, max |d| %.3g" % (rep, int((d > 1e-4).sum()), float(d.max()))
+
+
+# ---- dense 3x3 layers on the split form (ffgpu_conv_x3.inc) inside a PLANNED net: plan-time image, MT frozen in the plan, fused shortcut,
+# ragged widths (52 -> 26 -> 13), maxpool / route / upsample around them -- a darknet-tiny-style backbone
+def _c(filters, size, stride, act, bn=1):
+    return "[convolutional]\n%sfilters=%d\nsize=%d\nstride=%d\npad=1\nactivation=%s\n\n" % ("batch_normalize=1\n" if bn else "", filters, size, stride, act)
+
+
+DENSE3_CFG = "[net]\nwidth=104\nheight=104\nchannels=3\n\n" + _c(16, 3, 1, "leaky") + "[maxpool]\nsize=2\nstride=2\n\n" + _c(32, 3, 1, "leaky") + \
+    "[maxpool]\nsize=2\nstride=2\n\n" + _c(64, 3, 1, "leaky") + _c(64, 3, 1, "linear") + "[shortcut]\nfrom=-2\nactivation=leaky\n\n" + \
+    "[maxpool]\nsize=2\nstride=2\n\n" + _c(128, 3, 1, "leaky") + _c(40, 1, 1, "leaky") + _c(72, 3, 1, "leaky") + _c(21, 1, 1, "linear", bn=0) + \
+    "[yolo]\nmask = 0,1,2\nanchors = 6,8, 10,14, 20,18, 30,40, 50,44, 70,80\nclasses=2\nignore_thresh = .55\nscale_x_y = 1.05\n\n" + \
+    "[route]\nlayers = -4\n\n" + _c(24, 1, 1, "leaky") + "[upsample]\nstride=2\n\n" + "[route]\nlayers = -1, 5\n\n" + _c(48, 3, 1, "leaky") + _c(21, 1, 1, "linear", bn=0) + \
+    "[yolo]\nmask = 3,4,5\nanchors = 6,8, 10,14, 20,18, 30,40, 50,44, 70,80\nclasses=2\nignore_thresh = .55\nscale_x_y = 1.05\n\n"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [3, 16])
+def test_conv_x3_layers_in_an_executor(env, tmp_path, batch, monkeypatch):
+    from test_gpu_parity import _write_random_weights, close
+    capi, torch, orc = env
+    monkeypatch.setenv("FFGPU_IGX3_MIN_WGS", "1")                 # small planes too: every eligible layer on the split form
+    # the shapes of this cfg the split form must take (16 -> 32 on 52x52, 32 -> 64 / 64 -> 64 on 26x26, 64 -> 128 / 40 -> 72 on 13x13, 88 -> 48 on 26x26)
+    for (ic, oc, hw) in ((16, 32, 52), (32, 64, 26), (64, 64, 26), (64, 128, 13), (40, 72, 13), (88, 48, 26)):
+        assert capi.kernel_name(batch, hw, hw, ic, 1, 1, 1, 3, oc) == "conv_x3", (ic, oc, hw)
+    cfg = str(tmp_path / "dense3.cfg")
+    open(cfg, "w").write(DENSE3_CFG)
+    o = orc.Oracle(cfg=cfg, weights=None)
+    wpath = str(tmp_path / "dense3.weights")
+    _write_random_weights(wpath, o, 41)
+    o.close()
+    o = orc.Oracle(cfg=cfg, weights=wpath)
+    rng = np.random.default_rng(42)
+    frames = rng.uniform(0, 1, (batch, 3, 104, 104)).astype(np.float32)
+    with capi.Net(cfg, wpath) as n:
+        for flags in (capi.FFGPU.KEEP_ALL | capi.FFGPU.NO_FUSE, capi.FFGPU.KEEP_ALL, capi.FFGPU.CONCURRENT, capi.FFGPU.NO_GRAPH):
+            with n.executor(batch, flags) as ex:
+                ex.set_scale(1, 1)
+                for rep in range(2):                               # (the second forward replays the graph)
+                    ex.forward_host(frames)
+                for f in range(0, batch, 5):
+                    o.input[...] = frames[f]
+                    o.n.s1, o.n.s2 = 1, 1
+                    o.forward(0)
+                    seen = 0
+                    for i in range(o.nlayers):
+                        ref = o.layer_out(i)
+                        if ref is None or not (flags & capi.FFGPU.KEEP_ALL):
+                            continue
+                        try:
+                            a = ex.read_layer(i, f)
+                        except RuntimeError as e:
+                            assert "not materialised" in str(e)
+                            continue
+                        seen += 1
+                        close(a, ref, "dense3 cfg flags %d frame %d layer %d" % (flags, f, i))
+                    assert seen >= 8 or not (flags & capi.FFGPU.KEEP_ALL)
+                    got, want = ex.read_boxes(f), o.boxes
+                    assert abs(len(got) - len(want)) <= max(1, len(want) // 50), (flags, f, len(got), len(want))      # (a score within rounding of the threshold may flip)
+    o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 5, 11, 13, 27, 29])
+def test_random_generic_nets_with_conv_x3(tmp_path, seed, monkeypatch):
+    """the random generic nets of test_gpu_fuzz_nets.py with every eligible dense 3x3 layer forced onto the split form"""
+    from oracle import orc
+    from test_gpu_fuzz_nets import test_random_nets_fused_vs_oracle as run_net
+    orc.build()
+    monkeypatch.setenv("FFGPU_IGX3_MIN_WGS", "1")
+    monkeypatch.setenv("FFGPU_IGX3_MIN_IC", "8")
+    run_net(orc, tmp_path, seed, "generic")
