@@ -6,7 +6,8 @@
 # table, pointwise GEMM counters, igemm table, DW traffic from separate --pmc passes, ablation with four chains in flight)
 # + the issue budget of one forward of the plan the bench runs (FFGPU_CONCURRENT): instruction counts and matrix-pipe busy cycles per
 # kernel, counters only, one --pmc pass each
-# + round 4's tables: split-bf16 fused blocks against the fp32-MFMA form, k_pw_x3 against the fp32 pointwise kernels, DW variants.
+# + round 4's tables: split-bf16 fused blocks against the fp32-MFMA form, k_pw_x3 against the fp32 pointwise kernels, k_conv_x3 against the implicit
+# GEMM (+ its counters), the other nets with and without it, DW variants.
 set -u
 TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
@@ -26,6 +27,14 @@ rm -rf gpurun_out/pmc_issue
 timeout 300 tools/pmc.sh "k_pw_x3<" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INST_LEVEL_VMEM TCC_HIT_sum TCC_MISS_sum" -- python $R/tools/pw_gemm_bench.py 2>&1 | grep "k_pw_x3<" > gpurun_out/${TAG}_pw_x3_pmc.txt
 timeout 120 python tools/pw_gemm_bench.py 2>&1 | grep "pw_" >> gpurun_out/${TAG}_pw_x3_pmc.txt
 timeout 300 python tools/other_nets.py --table 2>&1 | grep -v amdgpu.ids | cut -c1-1600 > gpurun_out/${TAG}_other_nets.txt
+FFGPU_IG_X3=0 timeout 300 python tools/other_nets.py 2>&1 | grep -v amdgpu.ids | cut -c1-400 > gpurun_out/${TAG}_other_nets_fp32_igemm.txt
+# dense 3x3 layers: k_conv_x3 against k_conv_igemm, and its counters on four layers (matrix-pipe busy cycles against SQ_BUSY_CU_CYCLES x 4 SIMDs)
+timeout 300 python tools/conv_x3_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_conv_x3_vs_igemm.txt
+: > gpurun_out/${TAG}_conv_x3_pmc.txt
+for SH in "384 256 64 26 26" "512 1024 64 13 13" "64 128 64 52 52" "16 32 64 208 208"; do
+    timeout 120 python tools/conv_x3_one.py $SH 2>&1 | grep conv_x3 >> gpurun_out/${TAG}_conv_x3_pmc.txt
+    timeout 300 tools/pmc.sh "k_conv_x3<" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_INSTS_SALU TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" -- python $R/tools/conv_x3_one.py $SH 2>&1 | grep "k_conv_x3<" >> gpurun_out/${TAG}_conv_x3_pmc.txt
+done
 timeout 300 python tools/x3_error.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_x3_fused_blocks.txt
 timeout 300 python tools/pw_x3_bench.py 2>&1 | grep -v amdgpu.ids | cut -c1-420 > gpurun_out/${TAG}_pw_x3.txt
 timeout 300 python tools/dw_variants.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_dw_variants.txt
