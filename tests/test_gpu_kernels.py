@@ -294,6 +294,41 @@ def test_conv_x3(env, orc, shape, mt, nw, monkeypatch):
             assert np.all(np.abs(g - o) <= bound + 2.0 ** -22 * np.abs(o) + 1e-30), float(np.max(np.abs(g - o) / (bound + 1e-30)))
 
 
+PW_X3S_SHAPES = [  # (ic, oc, N, H, W, act): the heads' layers of yolo-fastest and ragged relatives (channels in blocks of 8, pixels in quads)
+    (120, 255, 64, 20, 20, 0), (120, 120, 16, 20, 20, 2), (96, 255, 64, 10, 10, 0), (192, 96, 8, 10, 10, 2), (8, 16, 1, 2, 2, 2), (40, 33, 3, 6, 10, 3),
+    (136, 24, 5, 20, 20, 0), (224, 48, 2, 10, 10, 1), (16, 70, 7, 4, 9, 2), (256, 130, 1, 13, 12, 2),
+]
+
+
+@pytest.mark.parametrize("mt,nw", [(0, 4), (4, 8), (2, 4), (1, 4)])
+@pytest.mark.parametrize("shape", PW_X3S_SHAPES)
+def test_pw_x3s(env, orc, shape, mt, nw, monkeypatch):
+    """the pointwise form of k_conv_x3 (FS = 1: one k-step per group, weights streamed by LDS-DMA, four waves per workgroup) -- the split-bf16 kernel for the
+    SMALL 1x1 layers; same checks as test_conv_x3"""
+    capi, torch = env
+    if mt:
+        monkeypatch.setenv("FFGPU_IGX3_MT", str(mt))
+    monkeypatch.setenv("FFGPU_IGX3_NW", str(nw))
+    ic, oc, N, H, W, act = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f = make_filter(rng, oc, ic)
+    f[:, :ic] *= 3.0 / np.sqrt(ic)
+    assert capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc, capi.FFGPU.K_CONV_X3) == "pw_x3s"
+    got = run_dev(capi, torch, x, f, N, W, H, ic, 1, 0, 1, 1, oc, act, capi.FFGPU.K_CONV_X3)
+    ref = run_dev(capi, torch, x, f, N, W, H, ic, 1, 0, 1, 1, oc, act, capi.FFGPU.K_GENERIC)
+    check(got, ref, "pw_x3s %s vs generic" % (shape,))
+    xf = x.reshape(ic, N, H, W)
+    k4 = (ic + 3) & ~3
+    for n in range(0, N, 7):
+        o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, 1, 0, 1, 1, act)
+        g = got.reshape(oc, N, H, W)[:, n]
+        check(g, o, "pw_x3s %s frame %d vs oracle" % (shape, n))
+        if act != 3:
+            bound = 2.0 ** -20 * np.abs(f[:, k4])[:, None, None] * np.einsum("ok,khw->ohw", np.abs(f[:, :ic]).astype(np.float64), np.abs(xf[:, n]).astype(np.float64))
+            assert np.all(np.abs(g - o) <= bound + 2.0 ** -22 * np.abs(o) + 1e-30), float(np.max(np.abs(g - o) / (bound + 1e-30)))
+
+
 def test_conv_x3_auto_pick(env, monkeypatch):
     """AUTO gives the big 3x3 layers of a darknet backbone to conv_x3, keeps k_conv_igemm (split-K) for launches that would not fill the chip,
     and FFGPU_IG_X3=0 switches it off"""
@@ -449,7 +484,7 @@ def test_pw_bf16(env, orc, shape):
         worst = max(worst, float(err.max()))
     assert worst > 1e-5, "bf16 variant returned fp32-exact results: it did not run"
     # AUTO never picks it unless the flag is passed
-    assert capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc) in ("pw_gemm", "pw_mfma", "pw_x3")
+    assert capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc) in ("pw_gemm", "pw_mfma", "pw_x3", "pw_x3s")
 
 
 def test_unsupported_variant_fails_loudly(env):
