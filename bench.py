@@ -269,14 +269,14 @@ def pw_roofline(torch, capi, stream):
         pass
     kname = capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc)
     note = None
-    if kname == "pw_x3":
+    if kname in ("pw_x3", "pw_x3s"):
         note = ("fp32-equivalent results from split operands: every fp32 value = three exact bf16 parts, six partial products per multiply-add on "
-                "v_mfma_f32_16x16x32_bf16, fp32 accumulation (ffgpu_pw_x3.inc; error as an fp32 summation order, tests/test_gpu_kernels.py::test_pw_x3). "
+                "v_mfma_f32_16x16x32_bf16, fp32 accumulation (ffgpu_conv_x3.inc, pointwise form; error as an fp32 summation order, tests/test_gpu_kernels.py::test_pw_x3s). "
                 "`frac` stays priced against the fp32 matrix peak the reference's arithmetic implies (the fp32 MFMAs run at the fp32 vector rate: 157.3 TFLOP/s); "
                 "against what this form could reach -- the bf16 dense peak / 6 products = 416.7 TFLOP/s -- it is `frac_of_bf16_peak_over_6`")
     return {"bf16_opt_in": bf, "fp32_mfma_kernel": f32k, "bound": "mfma", "kernel": kname, "achieved": round(tfs, 2),
             "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(tfs / FP32_MFMA_PEAK_TF, 4),
-            "frac_of_bf16_peak_over_6": round(tfs / (2500.0 / 6.0), 4) if kname == "pw_x3" else None, "note": note,
+            "frac_of_bf16_peak_over_6": round(tfs / (2500.0 / 6.0), 4) if kname in ("pw_x3", "pw_x3s") else None, "note": note,
             "us_per_launch": round(us, 2), "dtype": "f32",
             "workload": "pw1x1 256->512 20x20 batch 256 fp32 (BASELINE config[2])"}
 

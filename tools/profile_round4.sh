@@ -23,9 +23,15 @@ for CTRS in "SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS
     [ -n "$DB" ] && python tools/pmc_total.py "$DB" $REPS >> gpurun_out/${TAG}_issue_budget.txt
 done
 rm -rf gpurun_out/pmc_issue
-# the pointwise kernel AUTO picks for config[2] since round 4 (k_pw_x3) under the counters; profile_round2.sh's table above is k_pw_gemm32's (FFGPU_PW_X3=0)
+# the pointwise kernels of round 4 for config[2] under the counters: AUTO = the pointwise form of k_conv_x3 ("pw_x3s"), and k_pw_x3 (FFGPU_PW_X3S=0);
+# profile_round2.sh's table above is k_pw_gemm32's (FFGPU_PW_X3=0 FFGPU_PW_X3S=0)
+timeout 300 tools/pmc.sh "k_conv_x3<" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VMEM TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" -- python $R/tools/pw_gemm_bench.py 2>&1 | grep "k_conv_x3<" > gpurun_out/${TAG}_pw_x3s_pmc.txt
+timeout 120 python tools/pw_gemm_bench.py 2>&1 | grep "pw_" >> gpurun_out/${TAG}_pw_x3s_pmc.txt
+timeout 300 python tools/pw_x3s_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_pw_x3s.txt
+export FFGPU_PW_X3S=0
 timeout 300 tools/pmc.sh "k_pw_x3<" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INST_LEVEL_VMEM TCC_HIT_sum TCC_MISS_sum" -- python $R/tools/pw_gemm_bench.py 2>&1 | grep "k_pw_x3<" > gpurun_out/${TAG}_pw_x3_pmc.txt
 timeout 120 python tools/pw_gemm_bench.py 2>&1 | grep "pw_" >> gpurun_out/${TAG}_pw_x3_pmc.txt
+unset FFGPU_PW_X3S
 timeout 300 python tools/other_nets.py --table 2>&1 | grep -v amdgpu.ids | cut -c1-1600 > gpurun_out/${TAG}_other_nets.txt
 FFGPU_IG_X3=0 timeout 300 python tools/other_nets.py 2>&1 | grep -v amdgpu.ids | cut -c1-400 > gpurun_out/${TAG}_other_nets_fp32_igemm.txt
 # dense 3x3 layers: k_conv_x3 against k_conv_igemm, and its counters on four layers (matrix-pipe busy cycles against SQ_BUSY_CU_CYCLES x 4 SIMDs)
