@@ -81,6 +81,29 @@ def test_pw_x3_back_to_back(env, shape, mt, monkeypatch):
         assert not torch.isnan(y).any() and float(d.max()) <= 1e-4, "rep %d: %d outputs off, max |d| %.3g" % (rep, int((d > 1e-4).sum()), float(d.max()))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(120, 255, 64, 20, 20, 1), (256, 512, 64, 20, 20, 1), (96, 96, 64, 10, 10, 1), (64, 128, 16, 26, 26, 3), (32, 64, 8, 52, 52, 3)])
+def test_conv_x3_back_to_back(env, shape):
+    """both forms of k_conv_x3 (pointwise / 3x3) with leaky activation and random scale' / bias', 30 launches back to back, three times: the watch for
+    timing-dependent slips behind bf16 MFMAs (the dropped-addend hazard of section 5.10 showed only this way)"""
+    capi, torch, orc = env
+    ic, oc, N, H, W, fs = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f = make_filter(rng, oc, fs * fs * ic)
+    f[:, :fs * fs * ic] *= 3.0 / np.sqrt(fs * fs * ic)
+    pad = fs // 2
+    dx, df = torch.from_numpy(x).cuda(), torch.from_numpy(f).cuda()
+    ref = torch.empty((oc * N, H, W), device="cuda")
+    capi.groupconv_dev(dx.data_ptr(), df.data_ptr(), ref.data_ptr(), N, W, H, ic, 1, pad, 1, fs, oc, 2, 0, capi.FFGPU.K_PW_MFMA if fs == 1 else capi.FFGPU.K_IGEMM, None)
+    for rep in range(3):
+        y = torch.full((oc * N, H, W), float("nan"), device="cuda")
+        capi.groupconv_time_dev(dx.data_ptr(), df.data_ptr(), y.data_ptr(), N, W, H, ic, 1, pad, 1, fs, oc, act=2, variant=capi.FFGPU.K_CONV_X3, warmup=0, iters=30)
+        torch.cuda.synchronize()
+        d = (y - ref).abs()
+        assert not torch.isnan(y).any() and float(d.max()) <= 1e-4, "rep %d: %d outputs off, max |d| %.3g" % (rep, int((d > 1e-4).sum()), float(d.max()))
+
+
 # ---- dense 3x3 layers on the split form (ffgpu_conv_x3.inc) inside a PLANNED net: plan-time image, MT frozen in the plan, fused shortcut,
 # ragged widths (52 -> 26 -> 13), maxpool / route / upsample around them -- a darknet-tiny-style backbone
 def _c(filters, size, stride, act, bn=1):
