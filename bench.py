@@ -794,20 +794,25 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         fps = G * args.steps / dt
-        ok = None
+        ok = ok_all = None
         if check is not None:
             if host_dets:
                 rec = exs[shipped["group"]].dets_host()
             else:                                               # rank 0's block of the newest group, newest slot
                 blk = host[shipped["group"]][0].numpy()[shipped["slot"] * pbytes:(shipped["slot"] + 1) * pbytes]
                 rec = ffdist.unpack_records(blk, capi.DETS_DTYPE)
-            got = rec[0]["box"][: rec[0]["count"]]
             # u8 input: the library scales the boxes as net_input does for the image it is given (ffcnn.c:267-273: a 320x320 image -> factor 1);
             # the golden boxes are in the pixels of the 640-wide source the frame was letterboxed from (factor 640 / 320)
             bs = 2.0 if args.input == "u8" else 1.0
-            ok = bool(len(got) == len(check) and all(
-                int(a["type"]) == int(b["type"]) and abs(float(a["score"]) - float(b["score"])) < 1e-4 and
-                max(abs(bs * float(a[k]) - float(b[k])) for k in ("x1", "y1", "x2", "y2")) < 0.05 for a, b in zip(got, check)))
+
+            def golden(rec0):
+                got = rec0["box"][: rec0["count"]]
+                return bool(len(got) == len(check) and all(
+                    int(a["type"]) == int(b["type"]) and abs(float(a["score"]) - float(b["score"])) < 1e-4 and
+                    max(abs(bs * float(a[k]) - float(b[k])) for k in ("x1", "y1", "x2", "y2")) < 0.05 for a, b in zip(got, check)))
+            ok = golden(rec[0])
+            if host_dets:                                       # ... and the last step of EVERY chain (frame 0 of every input set is the test image)
+                ok_all = all(golden(e.dets_host()[0]) for e in exs)
         per_gpu_s = dt / args.steps                             # seconds per step; every GPU handles B frames of it
         u8 = args.input == "u8"
         in_what = "u8 BGR frames -> net_input's conversion in the first kernel -> " if u8 else ""
@@ -835,7 +840,8 @@ def main():
                        "executors": S, "pipelining": "%d executors on %d streams take the batches in turn%s" % (S, S, ", each split in two half-batch chains" if args.split else ""), "gather": ("RCCL gather of %d steps' records (packed: %d bytes per step and rank) + D2H on a side stream, overlapped with the next steps" % (M, pbytes)) if gather_mode else "records written to pinned host memory by the NMS kernel",
                        "graph_captures_per_executor": max(e.graph_captures for e in exs),     # (one per input format used: the u8 form of the first kernel has its own graph)
                        "weights": "data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL, untimed)",
-                       "boxes_match_reference_golden_frame0": ok},
+                       "boxes_match_reference_golden_frame0": ok,
+                       "boxes_match_reference_golden_frame0_every_chain": ok_all},
             # the whole net against the two ceilings that exist for it (per GPU): what the FUSED launch list must move
             # (each launch's inputs + outputs + filter rows once: ffgpu_exec_work_model) at the HBM peak, and the conv
             # stack's multiply-adds at the fp32 matrix peak.  Neither bounds the net tightly -- most launches are bound
