@@ -260,10 +260,16 @@ CONV_X3_SHAPES = [s for s in IGEMM_SHAPES if s[5:8] == (3, 1, 1) and s[4] >= 4 a
 ]
 
 
+CONV_X3_S2_SHAPES = [  # stride 2 (even planes, iw = 2 ow): the downsampling layers of yolov3 / yolov4-tiny; ragged output widths 5, 6, 13
+    (16, 32, 2, 24, 20, 3, 2, 1, 2), (32, 64, 1, 26, 26, 3, 2, 1, 2), (64, 130, 3, 8, 10, 3, 2, 1, 0), (8, 16, 1, 8, 8, 3, 2, 1, 2), (24, 40, 2, 16, 8, 3, 2, 1, 1),
+    (128, 96, 1, 52, 52, 3, 2, 1, 2), (40, 24, 5, 10, 12, 3, 2, 1, 2), (64, 64, 2, 28, 26, 3, 2, 1, 3), (32, 17, 4, 104, 104, 3, 2, 1, 2),
+]
+
+
 @pytest.mark.parametrize("mt,nw", [(0, 8), (4, 4), (2, 8), (1, 4)])
-@pytest.mark.parametrize("shape", CONV_X3_SHAPES)
+@pytest.mark.parametrize("shape", CONV_X3_SHAPES + CONV_X3_S2_SHAPES)
 def test_conv_x3(env, orc, shape, mt, nw, monkeypatch):
-    """dense 3x3 / stride 1 / pad 1 as SPLIT-bf16 products on the bf16 matrix cores (ffgpu_conv_x3.inc): against the generic kernel and the
+    """dense 3x3 / pad 1 (stride 1, and stride 2 on even planes) as SPLIT-bf16 products on the bf16 matrix cores (ffgpu_conv_x3.inc): against the generic kernel and the
     oracle with the tolerance of every fp32 kernel, and -- the claim of the kernel -- as close to the oracle as an fp32 reorder is:
     |d| <= 2^-20 * scale' * sum|w x| + 1 ulp.  All channel-tile heights (MT) and both workgroup sizes; widths that are not multiples of 4."""
     capi, torch = env
@@ -271,25 +277,26 @@ def test_conv_x3(env, orc, shape, mt, nw, monkeypatch):
         monkeypatch.setenv("FFGPU_IGX3_MT", str(mt))
     monkeypatch.setenv("FFGPU_IGX3_NW", str(nw))
     ic, oc, N, H, W, fs, stride, pad, act = shape
+    OH, OW = H // stride, W // stride
     K = 9 * ic
     rng = np.random.default_rng(hash(shape) & 0xffff)
     x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
     f = make_filter(rng, oc, K)
     f[:, :K] *= 3.0 / np.sqrt(K)
-    assert capi.kernel_name(N, W, H, ic, 1, 1, 1, 3, oc, capi.FFGPU.K_CONV_X3) == "conv_x3"
-    got = run_dev(capi, torch, x, f, N, W, H, ic, 1, 1, 1, 3, oc, act, capi.FFGPU.K_CONV_X3)
-    ref = run_dev(capi, torch, x, f, N, W, H, ic, 1, 1, 1, 3, oc, act, capi.FFGPU.K_GENERIC)
+    assert capi.kernel_name(N, W, H, ic, 1, 1, stride, 3, oc, capi.FFGPU.K_CONV_X3) == "conv_x3"
+    got = run_dev(capi, torch, x, f, N, W, H, ic, 1, 1, stride, 3, oc, act, capi.FFGPU.K_CONV_X3)
+    ref = run_dev(capi, torch, x, f, N, W, H, ic, 1, 1, stride, 3, oc, act, capi.FFGPU.K_GENERIC)
     check(got, ref, "conv_x3 %s vs generic" % (shape,))
     xf = x.reshape(ic, N, H, W)
     k4 = (K + 3) & ~3
     fa = np.abs(f)
     fa[:, k4], fa[:, k4 + 1] = 1.0, 0.0
     for n in range(N):
-        o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, 1, 1, 1, 3, act)
-        g = got.reshape(oc, N, H, W)[:, n]
+        o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, 1, 1, stride, 3, act)
+        g = got.reshape(oc, N, OH, OW)[:, n]
         check(g, o, "conv_x3 %s frame %d vs oracle" % (shape, n))
         if act != 3 and n == 0:
-            sabs = orc.groupconv(np.ascontiguousarray(np.abs(xf[:, n])), fa, 1, 1, 1, 3, 0).astype(np.float64)
+            sabs = orc.groupconv(np.ascontiguousarray(np.abs(xf[:, n])), fa, 1, 1, stride, 3, 0).astype(np.float64)
             bound = 2.0 ** -20 * np.abs(f[:, k4])[:, None, None] * sabs
             assert np.all(np.abs(g - o) <= bound + 2.0 ** -22 * np.abs(o) + 1e-30), float(np.max(np.abs(g - o) / (bound + 1e-30)))
 
@@ -335,7 +342,8 @@ def test_conv_x3_auto_pick(env, monkeypatch):
     capi, torch = env
     assert capi.kernel_name(16, 104, 104, 32, 1, 1, 1, 3, 64) == "conv_x3"
     assert capi.kernel_name(1, 13, 13, 256, 1, 1, 1, 3, 512) == "conv_igemm"
-    assert capi.kernel_name(16, 104, 104, 32, 1, 1, 2, 3, 64) == "conv_igemm"          # stride 2
+    assert capi.kernel_name(16, 104, 104, 32, 1, 1, 2, 3, 64) == "conv_x3"             # stride 2 on an even plane
+    assert capi.kernel_name(16, 13, 13, 32, 1, 1, 2, 3, 64) == "conv_igemm"            # ... an odd one
     assert capi.kernel_name(16, 104, 104, 36, 1, 1, 1, 3, 64) == "conv_igemm"          # input channels not in whole blocks of 8
     monkeypatch.setenv("FFGPU_IG_X3", "0")
     assert capi.kernel_name(16, 104, 104, 32, 1, 1, 1, 3, 64) == "conv_igemm"

@@ -118,24 +118,39 @@ DENSE3_CFG = "[net]\nwidth=104\nheight=104\nchannels=3\n\n" + _c(16, 3, 1, "leak
     "[yolo]\nmask = 3,4,5\nanchors = 6,8, 10,14, 20,18, 30,40, 50,44, 70,80\nclasses=2\nignore_thresh = .55\nscale_x_y = 1.05\n\n"
 
 
+# a yolov3-style backbone: 3x3 stride-2 downsampling layers, 1x1 / 3x3 residual blocks, two heads with a route + upsample
+DARK_CFG = "[net]\nwidth=96\nheight=128\nchannels=3\n\n" + _c(16, 3, 1, "leaky") + _c(32, 3, 2, "leaky") + _c(16, 1, 1, "leaky") + _c(32, 3, 1, "leaky") + \
+    "[shortcut]\nfrom=-3\nactivation=linear\n\n" + _c(64, 3, 2, "leaky") + _c(32, 1, 1, "leaky") + _c(64, 3, 1, "leaky") + "[shortcut]\nfrom=-3\nactivation=linear\n\n" + \
+    _c(128, 3, 2, "leaky") + _c(64, 1, 1, "leaky") + _c(128, 3, 1, "leaky") + "[shortcut]\nfrom=-3\nactivation=linear\n\n" + _c(21, 1, 1, "linear", bn=0) + \
+    "[yolo]\nmask = 0,1,2\nanchors = 6,8, 10,14, 20,18, 30,40, 50,44, 70,80\nclasses=2\nignore_thresh = .55\nscale_x_y = 1.05\n\n" + \
+    "[route]\nlayers = -3\n\n" + _c(32, 1, 1, "leaky") + "[upsample]\nstride=2\n\n" + "[route]\nlayers = -1, 8\n\n" + _c(64, 3, 1, "leaky") + _c(21, 1, 1, "linear", bn=0) + \
+    "[yolo]\nmask = 3,4,5\nanchors = 6,8, 10,14, 20,18, 30,40, 50,44, 70,80\nclasses=2\nignore_thresh = .55\nscale_x_y = 1.05\n\n"
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", ["tiny", "dark"])
 @pytest.mark.parametrize("batch", [3, 16])
-def test_conv_x3_layers_in_an_executor(env, tmp_path, batch, monkeypatch):
+def test_conv_x3_layers_in_an_executor(env, tmp_path, batch, which, monkeypatch):
     from test_gpu_parity import _write_random_weights, close
     capi, torch, orc = env
     monkeypatch.setenv("FFGPU_IGX3_MIN_WGS", "1")                 # small planes too: every eligible layer on the split form
-    # the shapes of this cfg the split form must take (16 -> 32 on 52x52, 32 -> 64 / 64 -> 64 on 26x26, 64 -> 128 / 40 -> 72 on 13x13, 88 -> 48 on 26x26)
-    for (ic, oc, hw) in ((16, 32, 52), (32, 64, 26), (64, 64, 26), (64, 128, 13), (40, 72, 13), (88, 48, 26)):
-        assert capi.kernel_name(batch, hw, hw, ic, 1, 1, 1, 3, oc) == "conv_x3", (ic, oc, hw)
+    if which == "tiny":
+        # the shapes of this cfg the split form must take (16 -> 32 on 52x52, 32 -> 64 / 64 -> 64 on 26x26, 64 -> 128 / 40 -> 72 on 13x13, 88 -> 48 on 26x26)
+        for (ic, oc, hw) in ((16, 32, 52), (32, 64, 26), (64, 64, 26), (64, 128, 13), (40, 72, 13), (88, 48, 26)):
+            assert capi.kernel_name(batch, hw, hw, ic, 1, 1, 1, 3, oc) == "conv_x3", (ic, oc, hw)
+    else:
+        # stride 2: 16 -> 32 from 96x128, 32 -> 64 from 48x64, 64 -> 128 from 24x32; stride 1: 16 -> 32 on 48x64, 32 -> 64 on 24x32, 64 -> 128 on 12x16, 96 -> 64 on 24x32
+        for (ic, oc, w, h, st) in ((16, 32, 96, 128, 2), (32, 64, 48, 64, 2), (64, 128, 24, 32, 2), (16, 32, 48, 64, 1), (32, 64, 24, 32, 1), (64, 128, 12, 16, 1), (96, 64, 24, 32, 1)):
+            assert capi.kernel_name(batch, w, h, ic, 1, 1, st, 3, oc) == "conv_x3", (ic, oc, w, h, st)
     cfg = str(tmp_path / "dense3.cfg")
-    open(cfg, "w").write(DENSE3_CFG)
+    open(cfg, "w").write(DENSE3_CFG if which == "tiny" else DARK_CFG)
     o = orc.Oracle(cfg=cfg, weights=None)
     wpath = str(tmp_path / "dense3.weights")
     _write_random_weights(wpath, o, 41)
     o.close()
     o = orc.Oracle(cfg=cfg, weights=wpath)
     rng = np.random.default_rng(42)
-    frames = rng.uniform(0, 1, (batch, 3, 104, 104)).astype(np.float32)
+    frames = rng.uniform(0, 1, (batch, 3, 104, 104) if which == "tiny" else (batch, 3, 128, 96)).astype(np.float32)
     with capi.Net(cfg, wpath) as n:
         for flags in (capi.FFGPU.KEEP_ALL | capi.FFGPU.NO_FUSE, capi.FFGPU.KEEP_ALL, capi.FFGPU.CONCURRENT, capi.FFGPU.NO_GRAPH):
             with n.executor(batch, flags) as ex:
@@ -207,3 +222,52 @@ def test_concurrent_executors_reproduce_themselves(batch, nexec):
         finally:
             for e in exs:
                 e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,force", [(2, True), (9, True), (4, False)])
+def test_dark3_cfg_against_the_oracle(env, tmp_path, batch, force, monkeypatch):
+    """tests/data/dark3.cfg (yolov3-shaped: 3x3 stride-2 downsampling layers, 1x1 + 3x3 residual blocks, two heads; what tools/other_nets.py times at 416x416) at
+    128x96 so that the oracle finishes in seconds: every layer and the boxes, with every eligible layer forced onto the split-bf16 kernels and with the default picks"""
+    from conftest import ROOT
+    from test_gpu_parity import _write_random_weights, close
+    capi, torch, orc = env
+    if force:
+        for k, v in (("FFGPU_IGX3_MIN_WGS", "1"), ("FFGPU_PWX3S_MIN_WGS", "1"), ("FFGPU_PWX3S_MIN_IC", "8"), ("FFGPU_PWX3S_MIN_OC", "8")):
+            monkeypatch.setenv(k, v)
+    txt = open(os.path.join(ROOT, "tests", "data", "dark3.cfg")).read().replace("width=416", "width=128").replace("height=416", "height=96")
+    cfg = str(tmp_path / "dark3_small.cfg")
+    open(cfg, "w").write(txt)
+    o = orc.Oracle(cfg=cfg, weights=None)
+    wpath = str(tmp_path / "dark3.weights")
+    _write_random_weights(wpath, o, 23)
+    o.close()
+    o = orc.Oracle(cfg=cfg, weights=wpath)
+    rng = np.random.default_rng(24)
+    frames = rng.uniform(0, 1, (batch, 3, 96, 128)).astype(np.float32)
+    refs = []
+    for f in range(batch):
+        o.input[...] = frames[f]
+        o.n.s1, o.n.s2 = 1, 1
+        o.forward(0)
+        refs.append(({i: o.layer_out(i).copy() for i in range(o.nlayers) if o.layer_out(i) is not None}, len(o.boxes)))
+    with capi.Net(cfg, wpath) as n:
+        assert n.layer_num == o.nlayers
+        if force:
+            names = set(capi.kernel_name(batch, L.w, L.h, L.c, 1, L.pad, L.stride, L.fs, L.fn) for L in (n.layer(i) for i in range(n.layer_num)) if L.type == 0)
+            assert "conv_x3" in names and "pw_x3s" in names, names
+        for flags in (capi.FFGPU.KEEP_ALL | capi.FFGPU.NO_FUSE, capi.FFGPU.KEEP_ALL, 0):
+            with n.executor(batch, flags) as ex:
+                ex.set_scale(1, 1)
+                ex.forward_host(frames)
+                for f in range(batch):
+                    if flags & capi.FFGPU.KEEP_ALL:
+                        for i, ref in refs[f][0].items():
+                            try:
+                                a = ex.read_layer(i, f)
+                            except RuntimeError as e:
+                                assert "not materialised" in str(e)
+                                continue
+                            close(a, ref, "dark3 flags %d frame %d layer %d" % (flags, f, i))
+                    assert abs(len(ex.read_boxes(f)) - refs[f][1]) <= max(1, refs[f][1] // 50), (flags, f)
+    o.close()

@@ -8,7 +8,11 @@ import torch
 from ffcnn_amd import capi
 SHAPES = [(16, 32, 16, 208, 208), (32, 64, 16, 104, 104), (64, 128, 16, 52, 52), (128, 256, 16, 26, 26), (256, 512, 16, 13, 13), (512, 1024, 16, 13, 13),
           (256, 512, 64, 13, 13), (16, 32, 64, 208, 208), (64, 128, 64, 52, 52), (512, 1024, 64, 13, 13), (384, 256, 64, 26, 26)]
-if len(sys.argv) > 1:
+ST = 1
+if len(sys.argv) > 1 and sys.argv[1] == "s2":        # the stride-2 form: the downsampling layers of a yolov3-style backbone (input planes given)
+    ST = 2
+    SHAPES = [(32, 64, 8, 416, 416), (64, 128, 16, 208, 208), (128, 256, 16, 104, 104), (256, 512, 16, 52, 52), (512, 1024, 16, 26, 26), (512, 1024, 64, 26, 26), (32, 64, 16, 208, 208)]
+elif len(sys.argv) > 1:
     SHAPES = SHAPES[:int(sys.argv[1])]
 s = torch.cuda.Stream()
 os.environ["FFGPU_IGX3_MIN_WGS"] = "1"
@@ -18,7 +22,8 @@ for (ic, oc, N, H, W) in SHAPES:
     filt = torch.zeros((oc, ((K + 3) & ~3) + 4), device="cuda")
     filt[:, :K] = (torch.rand((oc, K), device="cuda") - 0.5) / K ** 0.5
     filt[:, (K + 3) & ~3] = 1.0
-    fl = 2.0 * K * oc * N * H * W
+    OH, OW = H // ST, W // ST
+    fl = 2.0 * K * oc * N * OH * OW
     res = {}
     outs = {}
     for name, env in (("igemm", {"FFGPU_IG_X3": "0"}), ("x3 mt4 nw8", {"FFGPU_IGX3_MT": "4", "FFGPU_IGX3_NW": "8"}), ("x3 mt2 nw8", {"FFGPU_IGX3_MT": "2", "FFGPU_IGX3_NW": "8"}),
@@ -27,9 +32,9 @@ for (ic, oc, N, H, W) in SHAPES:
             os.environ.pop(k, None)
         os.environ.update(env)
         want = "conv_igemm" if name == "igemm" else "conv_x3"
-        assert capi.kernel_name(N, W, H, ic, 1, 1, 1, 3, oc) == want, (name, capi.kernel_name(N, W, H, ic, 1, 1, 1, 3, oc))
-        y = torch.full((oc * N, H, W), float("nan"), device="cuda")
-        res[name] = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 1, 1, 3, oc, act=2, variant=0,
+        assert capi.kernel_name(N, W, H, ic, 1, 1, ST, 3, oc) == want, (name, capi.kernel_name(N, W, H, ic, 1, 1, ST, 3, oc))
+        y = torch.full((oc * N, OH, OW), float("nan"), device="cuda")
+        res[name] = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 1, ST, 3, oc, act=2, variant=0,
                                             warmup=2, iters=20, stream=s.cuda_stream)
         torch.cuda.synchronize()
         outs[name] = y

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the SAME executor on what SURVEY 8(f) rows 2 / 3 name beside yolo-fastest at 320x320: another darknet cfg
-(tests/data/tiny3.cfg, yolov3-tiny-shaped: dense 3x3 stack on the implicit-GEMM kernel; random weights, 416x416) and yolo-fastest at
+(tests/data/tiny3.cfg, yolov3-tiny-shaped, and tests/data/dark3.cfg, yolov3-shaped with 3x3 stride-2 layers and residual blocks: random weights, 416x416) and yolo-fastest at
 the reference CLI's geometry (640x448, ffcnn.c:574).  Batch 16 per step, four chains; frames/s + the per-launch table of one chain.
 Used by bench.py (config.other_nets) and stand-alone:  python tools/other_nets.py [--table]"""
 import os, sys, time
@@ -66,6 +66,13 @@ def rows(torch, capi, table=False, tmpdir="/tmp"):
         r = [rate(torch, capi, cfg3, w3, 416, 416, table=table)]
     finally:
         os.unlink(w3)
+    cfgd = os.path.join(ROOT, "tests", "data", "dark3.cfg")                  # yolov3-shaped (reduced depth): 3x3 stride-2 layers + residual blocks
+    wd = os.path.join(tmpdir, "dark3_bench_%d.weights" % os.getpid())
+    write_random_weights(capi, cfgd, wd, 416, 416)
+    try:
+        r.append(rate(torch, capi, cfgd, wd, 416, 416, steps=40, table=table))
+    finally:
+        os.unlink(wd)
     r.append(rate(torch, capi, capi.CFG, capi.WEIGHTS, 640, 448, table=table))
     return r
 
