@@ -71,27 +71,30 @@ def test_dw3_stream(env, orc, shape, U, NT, monkeypatch):
 
 @pytest.mark.parametrize("shape", [(3, 8, 2, 64, 96, 2), (3, 8, 1, 8, 8, 2), (3, 5, 3, 16, 40, 0), (3, 12, 2, 24, 16, 1), (3, 8, 1, 320, 320, 2)])
 @pytest.mark.parametrize("first", [0, 1])
-def test_dense_first_layer(env, orc, shape, first, monkeypatch):
-    """3x3 stride-2 dense conv from 3 channels: k_conv_dense8 (first=0) and the four-pixels-per-thread k_conv_first
-    (first=1, forced on small batches) against the generic kernel, each other (bit for bit) and the oracle"""
+@pytest.mark.parametrize("stride", [2, 1])
+def test_dense_first_layer(env, orc, shape, first, stride, monkeypatch):
+    """3x3 dense conv from 3 channels, stride 2 (yolo-fastest) and stride 1 (the other darknet cfgs): k_conv_dense8 (first=0) and the
+    four-pixels-per-thread k_conv_first (first=1, forced on small batches) against the generic kernel, each other (bit for bit) and the oracle"""
     capi, torch = env
     ic, oc, N, H, W, act = shape
+    if stride == 1:
+        oc = 2 * oc + 3                                   # (16 / 32 filters there: several blocks of 8, a ragged last one)
     monkeypatch.setenv("FFGPU_CONV_FIRST_MIN_PX", "1")
     monkeypatch.setenv("FFGPU_NO_CONV_FIRST", "0" if first else "1")
     rng = np.random.default_rng(hash(shape) & 0xffff)
     x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
     f = make_filter(rng, oc, 9 * ic)
-    got = run_dev(capi, torch, x, f, N, W, H, ic, 1, 1, 2, 3, oc, act, capi.FFGPU.K_DENSE_SMALL)
-    ref = run_dev(capi, torch, x, f, N, W, H, ic, 1, 1, 2, 3, oc, act, capi.FFGPU.K_GENERIC)
+    got = run_dev(capi, torch, x, f, N, W, H, ic, 1, 1, stride, 3, oc, act, capi.FFGPU.K_DENSE_SMALL)
+    ref = run_dev(capi, torch, x, f, N, W, H, ic, 1, 1, stride, 3, oc, act, capi.FFGPU.K_GENERIC)
     check(got, ref, "dense first %s vs generic" % (shape,))
     monkeypatch.setenv("FFGPU_NO_CONV_FIRST", "1")
-    other = run_dev(capi, torch, x, f, N, W, H, ic, 1, 1, 2, 3, oc, act, capi.FFGPU.K_DENSE_SMALL)
+    other = run_dev(capi, torch, x, f, N, W, H, ic, 1, 1, stride, 3, oc, act, capi.FFGPU.K_DENSE_SMALL)
     assert np.array_equal(got, other), "k_conv_first and k_conv_dense8 differ"
     if H * W * N <= 20000:
         xf = x.reshape(ic, N, H, W)
         for n in range(N):
-            o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, 1, 1, 2, 3, act)
-            check(got.reshape(oc, N, H // 2, W // 2)[:, n], o, "dense first %s frame %d vs oracle" % (shape, n))
+            o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, 1, 1, stride, 3, act)
+            check(got.reshape(oc, N, H // stride, W // stride)[:, n], o, "dense first %s frame %d vs oracle" % (shape, n))
 
 
 PW_SHAPES = [  # (ic, oc, N, H, W, act)
