@@ -28,7 +28,8 @@ def write_random_weights(capi, cfg, path, w, h, seed=7):
                 fp.write(rng.uniform(0.5, 1.5, L.fn).astype("<f4").tobytes())
                 fp.write(rng.uniform(-0.3, 0.3, L.fn).astype("<f4").tobytes())
                 fp.write(rng.uniform(0.2, 1.0, L.fn).astype("<f4").tobytes())
-            fp.write((rng.uniform(-1, 1, L.fn * K) * (1.6 / np.sqrt(K))).astype("<f4").tobytes())
+            # (... and small taps for them: with 1024 inputs of unit scale the pre-activations otherwise spread over +-5 and a bias of -6 no longer keeps them down)
+            fp.write((rng.uniform(-1, 1, L.fn * K) * ((1.6 if L.activation != 0 else 0.1) / np.sqrt(K))).astype("<f4").tobytes())
 
 
 def rate(torch, capi, cfg, weights, w, h, batch=16, chains=4, steps=80, table=False):
