@@ -107,6 +107,21 @@ __global__ void k_pool(const float *in, float *out, long planes, int w, int h, i
     }
 }
 
+// the 2x2 / stride 2 max pool of the darknet-tiny backbones on planes whose width is a multiple of 8: a thread owns FOUR adjacent outputs = two rows of eight
+// inputs (four 16-byte loads, one 16-byte store, 32-bit offsets); same comparisons in the same order as k_pool (row, then column)
+typedef float v4f_pl __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_pool2x2(const float *in, float *out, unsigned nquads, unsigned owq, unsigned m_owq, int w)
+{
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= nquads) return;
+    const unsigned row = owq == 1 ? t : __umulhi(t, m_owq), xq = t - row * owq;      // row = (plane, output row): input rows 2 row, 2 row + 1 (h even)
+    const gfp src = to_global(in) + ((size_t)row * 2u * (unsigned)w + 8u * xq);
+    const v4f_pl a0 = gld<v4f_pl>(src), a1 = gld<v4f_pl>(src + 4), b0 = gld<v4f_pl>(src + w), b1 = gld<v4f_pl>(src + w + 4);
+    auto mx = [](float p00, float p01, float p10, float p11) { float v = p00; v = v < p01 ? p01 : v; v = v < p10 ? p10 : v; v = v < p11 ? p11 : v; return v; };
+    const v4f_pl r = { mx(a0.x, a0.y, b0.x, b0.y), mx(a0.z, a0.w, b0.z, b0.w), mx(a1.x, a1.y, b1.x, b1.y), mx(a1.z, a1.w, b1.z, b1.w) };
+    *reinterpret_cast<v4f_pl *>(out + (size_t)t * 4) = r;
+}
+
 // several stride-1 max pools of ONE tensor (the SPP block of a yolo cfg: 3x3, 5x5, 9x9 of the same 10x10 planes) in one
 // launch: a plane is staged in LDS once and every window size is read from there (same clipping as k_pool)
 struct SppP { const float *in; float *out[3]; int fs[3]; int n; long planes; int w, h; int cascade; };
@@ -552,6 +567,16 @@ int ffgpu_launch_pool(const float *in, float *out, int N, int c, int w, int h, i
 {
     if (stride < 1 || fs < 1) { ffgpu_set_error("pool: bad size/stride"); return -1; }
     const long planes = (long)N * c, total = planes * (h / stride) * (w / stride);
+    if (is_max && fs == 2 && stride == 2 && w % 8 == 0 && h % 2 == 0 && total < (1L << 32) && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0 && !getenv("FFGPU_NO_POOL2X2")) {
+        const unsigned owq = (unsigned)(w / 8), nquads = (unsigned)(total / 4);
+        const unsigned m = owq == 1 ? 0u : (unsigned)(((1ULL << 32) + owq - 1) / owq);
+        if ((unsigned long long)nquads * owq < (1ULL << 32))         // (umulhi division exact)
+        {
+        hipLaunchKernelGGL(k_pool2x2, dim3((nquads + 255) / 256), dim3(256), 0, s, in, out, nquads, owq, m, w);
+        LAUNCH_OK("pool2x2");
+        return 0;
+        }
+    }
     hipLaunchKernelGGL(k_pool, dim3(grid_for(total, 256)), dim3(256), 0, s, in, out, planes, w, h, fs, stride, is_max);
     LAUNCH_OK("pool");
     return 0;
