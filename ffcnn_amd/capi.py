@@ -17,7 +17,7 @@ f32p = C.POINTER(C.c_float)
 class FFGPU:
     MAX_DET = 128
     KEEP_ALL, COMPAT_V6, NO_GRAPH, NO_FUSE, HOST_DETS, SPLIT2, CONCURRENT, BF16_PW = 1, 2, 4, 8, 16, 32, 64, 128
-    K_AUTO, K_GENERIC, K_DW_STREAM, K_DW_LDS, K_PW_MFMA, K_PW_GEMM, _K6, K_DENSE_SMALL, K_IGEMM, K_PW_BF16, K_GROUP_THIN, K_PW_X3, K_CONV_X3 = range(13)
+    K_AUTO, K_GENERIC, K_DW_STREAM, K_DW_LDS, K_PW_MFMA, K_PW_GEMM, _K6, K_DENSE_SMALL, K_IGEMM, K_PW_BF16, K_GROUP_THIN, K_PW_X3, K_CONV_X3, K_PW_X3T = range(14)
 
 
 class LAYER(C.Structure):            # include/ffcnn.h (120 bytes)
@@ -108,6 +108,9 @@ def lib():
     L.groupconv.argtypes = [f32p, f32p, f32p] + [i] * 12 + [C.POINTER(f32p), C.POINTER(i)]
     L.ffgpu_last_error.restype = C.c_char_p
     L.ffgpu_build_info.restype = C.c_char_p
+    # a lab build (make DIAG=1: FFGPU_DBG_SKIP / FFGPU_DBG_KEEP drop launches, results are wrong by design) is only loaded when the caller says so
+    if b" DIAG " in L.ffgpu_build_info() and os.environ.get("FFCNN_HIP_ALLOW_DIAG") != "1":
+        raise RuntimeError("%s is a DIAG (lab) build of libffcnn_hip; set FFCNN_HIP_ALLOW_DIAG=1 to load it on purpose" % path)
     L.ffgpu_set_device.argtypes = [i]
     L.ffgpu_net_weights_dev.argtypes = [C.POINTER(NET), C.POINTER(vp), C.POINTER(sz)]
     L.ffgpu_net_weights_commit.argtypes = [C.POINTER(NET), vp]

@@ -35,8 +35,14 @@ struct ConvDesc {
     int   res_act;        // activation applied after adding the residual
     int   flags;          // FFGPU_COMPAT_V6
     long  in_cs, in_ns, out_cs, out_ns, res_cs, res_ns;
-    int   nsplit;         // implicit-GEMM split-K factor frozen at plan time (ffgpu_conv_plan_split); 0 = decided at launch (single-layer calls)
+    int   nsplit;         // implicit-GEMM split-K factor frozen at plan time (ffgpu_conv_plan); 0 = decided at launch (single-layer calls)
+    int   kernel;         // FFGPU_K_* frozen at plan time (ffgpu_conv_plan): ffgpu_launch_conv(AUTO), the pack size and the pack kernel all follow it,
+                          // so a later change of the FFGPU_* tuning environment cannot pair one kernel with another kernel's weight image; 0 = pick at launch
+    int   x3_mt;          // k_conv_x3's MT (16-row blocks per wave: the layout of its packed image) frozen with the plan; 0 = decided at launch
 };
+// internal bit of ConvDesc::flags (never part of the public flag set): the step reads the executor's BATCH INPUT (frame-major, possibly through the
+// parameter block) -- kernels that cannot read through ConvDesc::in_ind are not picked for it, so the one-graph-for-every-input property survives
+#define FFGPU_F_BATCH_INPUT (1 << 30)
 
 static inline int conv_k4(const ConvDesc &d) { return (d.fs * d.fs * (d.ic / d.groups) + 3) & ~3; }
 
@@ -64,7 +70,7 @@ int    ffgpu_dwpw_pack(const ConvDesc &dw, const ConvDesc &pw, float *pk, hipStr
 int    ffgpu_launch_dwpw(const ConvDesc &dw, const ConvDesc &pw, const float *wpack, hipStream_t s);
 
 size_t ffgpu_pw_pack_floats(const ConvDesc &d);
-int    ffgpu_conv_plan_split(const ConvDesc &d);       // the split-K factor k_conv_igemm would pick for this layer NOW (environment read once, here)
+void   ffgpu_conv_plan(ConvDesc &d);                   // freezes kernel / nsplit / x3_mt for this layer NOW (the tuning environment is read once, here)
 int    ffgpu_pw_pack(const ConvDesc &d, float *pk, hipStream_t s);
 
 // Per-executor parameter block in device memory: what changes from one forward to the next without changing the

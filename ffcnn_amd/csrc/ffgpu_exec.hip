@@ -43,7 +43,11 @@ extern "C" const char *ffgpu_last_error(void) { return g_err; }
 
 extern "C" const char *ffgpu_build_info(void)
 {
+#ifdef FFGPU_DIAG
+    return "libffcnn_hip gfx950 (CDNA4) HIP DIAG (lab build: launch-dropping switches compiled in) " __DATE__ " " __TIME__;
+#else
     return "libffcnn_hip gfx950 (CDNA4) HIP " __DATE__ " " __TIME__;
+#endif
 }
 
 extern "C" int ffgpu_device_count(void)
@@ -593,7 +597,11 @@ static int plan(ffgpu_exec *ex)
         size_t tot = 0;
         for (Step &st : S) {
             if (st.kind == S_IRB) tot += ffgpu_irb_pack_floats(st.irb);
-            if (st.kind == S_CONV) { st.conv.nsplit = ffgpu_conv_plan_split(st.conv); tot += ffgpu_pw_pack_floats(st.conv); }    // (split-K frozen with the plan)
+            if (st.kind == S_CONV) {                              // kernel choice, split-K and k_conv_x3's MT frozen with the plan
+                if (st.in_is_input) st.conv.flags |= FFGPU_F_BATCH_INPUT;
+                ffgpu_conv_plan(st.conv);
+                tot += ffgpu_pw_pack_floats(st.conv);
+            }
             if (st.kind == S_DWPW) tot += ffgpu_dwpw_pack_floats(st.conv, st.conv2);
         }
         if (tot) {

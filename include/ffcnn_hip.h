@@ -223,7 +223,8 @@ enum {
     FFGPU_K_PW_BF16 = 9,      /* 1x1, opt-in (FFGPU_BF16_PW): bf16 inputs, fp32 accumulation, v_mfma_f32_32x32x16_bf16 */
     FFGPU_K_GROUP_THIN = 10,  /* 2..7 input channels per group (grouped or dense), any fs / stride / pad: scalar filter taps, several outputs per lane */
     FFGPU_K_PW_X3 = 11,       /* 1x1: fp32-equivalent results from SPLIT operands (three exact bf16 parts each, six partial products, fp32 accumulation) on v_mfma_f32_16x16x32_bf16 */
-    FFGPU_K_CONV_X3 = 12      /* dense 3x3 / stride 1 / pad 1, one group: the same split-operand arithmetic as FFGPU_K_PW_X3 (ffgpu_conv_x3.inc) */
+    FFGPU_K_CONV_X3 = 12,     /* dense 3x3 / stride 1 / pad 1, one group: the same split-operand arithmetic as FFGPU_K_PW_X3 (ffgpu_conv_x3.inc) */
+    FFGPU_K_PW_X3T = 13       /* 1x1: the same split-operand arithmetic as a tiled, double-buffered GEMM (ffgpu_pw_x3t.inc): every input value split once per 256 output channels */
 };
 
 /* name of the kernel `variant` resolves to for this shape (for logs/benches) */

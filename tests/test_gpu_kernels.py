@@ -339,6 +339,41 @@ def test_pw_x3s(env, orc, shape, mt, nw, monkeypatch):
             assert np.all(np.abs(g - o) <= bound + 2.0 ** -22 * np.abs(o) + 1e-30), float(np.max(np.abs(g - o) / (bound + 1e-30)))
 
 
+PW_X3T_SHAPES = [  # (ic, oc, N, H, W, act): BASELINE config[2]'s layer at a small batch, ragged K (72, 100, 120: partial chunks of 16; 8: half a chunk),
+    # ragged channel tiles (255, 300, 130, 21), one tile / main + narrow tiles / more than one round of workgroups, ragged last pixel tile, sigmoid, relu
+    (256, 512, 2, 20, 20, 2), (120, 255, 64, 20, 20, 0), (120, 120, 3, 20, 20, 2), (192, 96, 4, 10, 10, 2), (72, 300, 83, 20, 20, 2), (64, 256, 164, 20, 20, 0),
+    (80, 255, 170, 20, 20, 3), (100, 200, 1, 12, 12, 1), (33, 21, 1, 6, 6, 3), (8, 16, 2, 4, 4, 2), (16, 130, 5, 7, 12, 2), (256, 512, 40, 20, 20, 2),
+]
+
+
+@pytest.mark.parametrize("narrow", [1, 0])
+@pytest.mark.parametrize("shape", PW_X3T_SHAPES)
+def test_pw_x3t(env, orc, shape, narrow, monkeypatch):
+    """the TILED split-bf16 pointwise GEMM (ffgpu_pw_x3t.inc, round 5: every input value split once per 256 output channels by its workgroup, weights by
+    LDS-DMA, two LDS buffers, v_mfma_f32_32x32x16_bf16): the checks of test_pw_x3 -- every fp32 kernel's tolerance against the generic kernel and the oracle,
+    and the fp32-reorder bound |d| <= 2^-20 * scale' * sum|w x| + 1 ulp; with and without the narrow tiles of the partial last round"""
+    capi, torch = env
+    monkeypatch.setenv("FFGPU_PWXT_NARROW", str(narrow))
+    ic, oc, N, H, W, act = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f = make_filter(rng, oc, ic)
+    f[:, :ic] *= 3.0 / np.sqrt(ic)
+    assert capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc, capi.FFGPU.K_PW_X3T) == "pw_x3t"
+    got = run_dev(capi, torch, x, f, N, W, H, ic, 1, 0, 1, 1, oc, act, capi.FFGPU.K_PW_X3T)
+    ref = run_dev(capi, torch, x, f, N, W, H, ic, 1, 0, 1, 1, oc, act, capi.FFGPU.K_GENERIC)
+    check(got, ref, "pw_x3t %s vs generic" % (shape,))
+    xf = x.reshape(ic, N, H, W)
+    k4 = (ic + 3) & ~3
+    for n in sorted({0, N // 2, N - 1}):
+        o = orc.groupconv(np.ascontiguousarray(xf[:, n]), f, 1, 0, 1, 1, act)
+        g = got.reshape(oc, N, H, W)[:, n]
+        check(g, o, "pw_x3t %s frame %d vs oracle" % (shape, n))
+        if act != 3:
+            bound = 2.0 ** -20 * np.abs(f[:, k4])[:, None, None] * np.einsum("ok,khw->ohw", np.abs(f[:, :ic]).astype(np.float64), np.abs(xf[:, n]).astype(np.float64))
+            assert np.all(np.abs(g - o) <= bound + 2.0 ** -22 * np.abs(o) + 1e-30), float(np.max(np.abs(g - o) / (bound + 1e-30)))
+
+
 def test_conv_x3_auto_pick(env, monkeypatch):
     """AUTO gives the big 3x3 layers of a darknet backbone to conv_x3, keeps k_conv_igemm (split-K) for launches that would not fill the chip,
     and FFGPU_IG_X3=0 switches it off"""

@@ -75,7 +75,7 @@ def make_filter(rng, fn, K):
 
 
 # ------------------------------------------------------------------ config[2]: pointwise 256 -> 512 on 20x20
-@pytest.mark.parametrize("variant", ["K_PW_MFMA", "K_PW_GEMM", "K_PW_X3", "K_CONV_X3", "K_AUTO"])
+@pytest.mark.parametrize("variant", ["K_PW_MFMA", "K_PW_GEMM", "K_PW_X3", "K_CONV_X3", "K_PW_X3T", "K_AUTO"])
 @pytest.mark.parametrize("N,sample", [(2, (0, 1)), (256, (0, 1, 77, 128, 254, 255))])
 def test_pw_config2_against_oracle(F, orc, variant, N, sample):
     """input N x 256 x 20 x 20, 512 filter rows of 260 floats, leaky -- every sampled frame of the
@@ -87,7 +87,7 @@ def test_pw_config2_against_oracle(F, orc, variant, N, sample):
     f = make_filter(rng, oc, ic)
     v = getattr(F.FFGPU, variant)
     if N == 256 and variant == "K_AUTO":
-        assert F.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc) == "pw_x3s"         # what bench.py's roofline_pw times (round 4: split-bf16 products, streamed form)
+        assert F.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc) == "pw_x3t"         # what bench.py's roofline_pw times (round 5: split-bf16 products, tiled form)
     dx, df = torch.from_numpy(x).cuda(), torch.from_numpy(f).cuda()
     dy = torch.full((oc, N, H, W), float("nan"), device="cuda")
     F.groupconv_dev(dx.data_ptr(), df.data_ptr(), dy.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act, 0, v, None)

@@ -13,7 +13,7 @@ cp gpurun_out/dw3x3_traffic.txt gpurun_out/${TAG}_dw3x3_traffic.txt 2>/dev/null
 cp gpurun_out/dw3x3_traffic.json gpurun_out/${TAG}_dw3x3_traffic.json 2>/dev/null
 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 # ablation: the DIAG build of the library (tools/build_skip_lib.sh, built beforehand where the sources are: it travels with the snapshot)
-if [ -f ffcnn_amd/lib/libffcnn_hip_skip.so ]; then
-    FFCNN_HIP_LIB=$R/ffcnn_amd/lib/libffcnn_hip_skip.so timeout 600 python tools/ablate_layers.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_ablation_4streams.txt
+if [ -f tools/lab/lib/libffcnn_hip_skip.so ]; then
+    FFCNN_HIP_ALLOW_DIAG=1 FFCNN_HIP_LIB=$R/tools/lab/lib/libffcnn_hip_skip.so timeout 600 python tools/ablate_layers.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_ablation_4streams.txt
     tail -3 gpurun_out/${TAG}_ablation_4streams.txt
 fi
