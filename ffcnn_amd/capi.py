@@ -61,7 +61,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_net_weights_dev", "ffgpu_net_weights_commit",
            "ffgpu_exec_create", "ffgpu_exec_destroy", "ffgpu_exec_batch", "ffgpu_exec_arena_bytes",
            "ffgpu_exec_kernel_count", "ffgpu_exec_work_model", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
-           "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_set_ring", "ffgpu_exec_set_ring_strided", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer",
+           "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_set_ring", "ffgpu_exec_set_ring_strided", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer", "ffgpu_exec_hash_layers",
            "ffgpu_exec_read_boxes", "ffgpu_exec_cand_capacity", "ffgpu_exec_graph_captures",
            "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_dwpw_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records", "ffgpu_unpack_records",
            "ffgpu_shard_range", "ffgpu_node_create", "ffgpu_node_destroy", "ffgpu_node_ndev", "ffgpu_node_shard", "ffgpu_node_set_scale",
@@ -132,6 +132,7 @@ def lib():
     L.ffgpu_exec_set_ring_strided.argtypes = [vp, vp, C.c_int, C.c_int]
     L.ffgpu_exec_read_dets.argtypes = [vp, vp, i]
     L.ffgpu_exec_read_layer.argtypes = [vp, i, i, f32p, sz]
+    L.ffgpu_exec_hash_layers.argtypes = [vp, vp, i]
     L.ffgpu_exec_profile.argtypes = [vp, vp, f32p]
     L.ffgpu_exec_profile_steps.argtypes = [vp, vp, C.POINTER(i), f32p, i]
     L.ffgpu_groupconv_dev.argtypes = [vp, vp, vp] + [i] * 15 + [vp]
@@ -416,6 +417,12 @@ class Executor:
         shape = self.net.out_shape(layer) if layer >= 0 else self.net.input_shape
         out = np.empty(shape, np.float32)
         _check(lib().ffgpu_exec_read_layer(self.h, layer, frame, out.ctypes.data_as(f32p), out.size), "ffgpu_exec_read_layer")
+        return out
+
+    def hash_layers(self):
+        """one 64-bit hash per layer over the layer's whole batch tensor (0: not materialised); FFGPU.KEEP_ALL executors"""
+        out = np.zeros(self.net.layer_num, np.uint64)
+        _check(lib().ffgpu_exec_hash_layers(self.h, out.ctypes.data, out.size), "ffgpu_exec_hash_layers")
         return out
 
     @property

@@ -99,6 +99,7 @@ int ffgpu_launch_spp(const float *in, float *const out[3], const int fs[3], int 
 int ffgpu_launch_upsample(const float *in, float *out, long planes, int w, int h, int stride, hipStream_t s);
 int ffgpu_launch_add_act(const float *a, const float *b, float *out, long n, int act, hipStream_t s);
 int ffgpu_launch_copy(const float *src, float *dst, long n, hipStream_t s);
+int ffgpu_launch_hash64(const float *x, long n, unsigned long long *out, hipStream_t s);
 int ffgpu_launch_input_bgr(const unsigned char *bgr, float *out, int N, int w, int h, int W, int H,
                            int sw, int sh, int s1, int s2, const float mean[3], const float norm[3], hipStream_t s);
 

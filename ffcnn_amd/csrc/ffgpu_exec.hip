@@ -1224,6 +1224,34 @@ extern "C" int ffgpu_exec_read_boxes(ffgpu_exec *ex, int frame, BBOX *host_out, 
     return nfull;
 }
 
+// FFGPU_KEEP_ALL executors: one 64-bit hash per materialised layer over the layer's WHOLE batch tensor (every bit of every frame), computed on the
+// device behind the last forward; 0 for layers this executor does not materialise.  What the concurrency soak compares round after round
+// (tests/test_gpu_round5.py): 8 bytes per layer cross the bus instead of the activations.
+extern "C" int ffgpu_exec_hash_layers(ffgpu_exec *ex, unsigned long long *host_out, int cap)
+{
+    if (!alive(ex, "hash_layers")) return -1;
+    if (ex->child[0]) { ffgpu_set_error("hash_layers: not for FFGPU_SPLIT2 executors"); return -1; }
+    if (!(ex->flags & FFGPU_KEEP_ALL)) { ffgpu_set_error("hash_layers needs an FFGPU_KEEP_ALL executor"); return -1; }
+    const int L = ex->net->layer_num;
+    if (!host_out || cap < L) { ffgpu_set_error("hash_layers: room for %d values needed", L); return -1; }
+    unsigned long long *d = nullptr;
+    FFGPU_CHECK(hipMalloc(&d, sizeof(unsigned long long) * L));
+    hipStream_t s = ex->last_stream;
+    int rc = 0, nh = 0;
+    if (hipMemsetAsync(d, 0, sizeof(unsigned long long) * L, s) != hipSuccess) rc = -1;
+    for (int i = 0; i < L && !rc; i++) {
+        if (ex->canon[i] < 0 || !ex->readable[i]) continue;
+        const LAYER &o = ex->net->layer_list[i + 1];
+        if (ffgpu_launch_hash64(tensor_ptr(ex, ex->canon[i]), (long)o.c * ex->N * o.w * o.h, d + i, s)) rc = -1;
+        nh++;
+    }
+    if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = -1;
+    if (!rc && copy_d2h(host_out, d, sizeof(unsigned long long) * L)) rc = -1;
+    (void)hipFree(d);
+    if (rc) { ffgpu_set_error("hash_layers: a device call failed"); return -1; }
+    return nh;
+}
+
 extern "C" int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float *host_out, size_t cap_floats)
 {
     if (!alive(ex, "read_layer")) return -1;

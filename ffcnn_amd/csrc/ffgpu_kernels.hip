@@ -615,6 +615,26 @@ int ffgpu_launch_add_act(const float *a, const float *b, float *out, long n, int
     return 0;
 }
 
+// position-dependent 64-bit hash of a tensor's bits: sum over i of mix(bits[i], i) mod 2^64 -- integer addition, so the result does not depend on the
+// order the threads arrive in (ffgpu_exec_hash_layers: every bit of every frame of a layer in one number, compared on the host)
+__global__ void k_hash64(const unsigned *x, long n, unsigned long long *out)
+{
+    unsigned long long h = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned long long v = ((unsigned long long)x[i] << 32 | (unsigned long long)(unsigned)i) + 0x9e3779b97f4a7c15ull * (unsigned long long)(i >> 32);
+        v ^= v >> 30; v *= 0xbf58476d1ce4e5b9ull; v ^= v >> 27; v *= 0x94d049bb133111ebull; v ^= v >> 31;      // splitmix64 finaliser
+        h += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+int ffgpu_launch_hash64(const float *x, long n, unsigned long long *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_hash64, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, s, reinterpret_cast<const unsigned *>(x), n, out);
+    LAUNCH_OK("hash64");
+    return 0;
+}
+
 int ffgpu_launch_copy(const float *src, float *dst, long n, hipStream_t s)
 {
     hipLaunchKernelGGL(k_copy, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, s, src, dst, n);

@@ -21,6 +21,17 @@
  * drop-in use and per-layer parity, not for throughput (use ffcnn_hip.h).
  * On a HIP failure it prints a diagnostic to stderr and leaves `out` untouched,
  * mirroring the reference's printf-and-return error path (conv-v6.c:509).
+ *
+ * Arithmetic: fp32 results within the repo's stated tolerance of the reference's
+ * k-ordered chain (conv-v0.c:7-31) for every finite input.  The kernels AUTO
+ * picks for dense 3x3 layers and large 1x1 layers compute each product from
+ * three exact bf16 parts per operand on the bf16 matrix cores (24 significand
+ * bits kept, fp32 accumulation: a summation ORDER, not a precision).  ONE
+ * documented difference (tests/test_gpu_round5.py::test_x3_non_finite_lanes):
+ * a +-Inf INPUT value makes every output whose window holds it NaN there, where
+ * the reference gives +-Inf unless the Inf meets a zero tap or an opposite Inf
+ * (both results are non-finite; no other output is affected).  Sub-normal
+ * inputs and magnitudes spread over 2^-30 .. 2^30 in one sum behave like fp32.
  */
 #ifndef FFCNN_AMD_CONV_H
 #define FFCNN_AMD_CONV_H

@@ -146,6 +146,14 @@ int ffgpu_exec_graph_captures(const ffgpu_exec *ex);    /* HIP graphs captured s
  * pixels, reference emission order) and returns their count. */
 int ffgpu_exec_read_layer(ffgpu_exec *ex, int layer, int frame, float *host_out, size_t cap_floats);
 
+/* FFGPU_KEEP_ALL executors only: host_out[i] = a 64-bit position-dependent hash of
+ * layer i's output over the WHOLE batch (every bit of every frame; computed on
+ * the device behind the last forward), 0 for layers this executor does not
+ * materialise.  cap >= NET.layer_num.  Returns the number of layers hashed.
+ * Two forwards of the same frames must give the same values: the reproducibility
+ * watch of the concurrency tests reads 8 bytes per layer instead of activations. */
+int ffgpu_exec_hash_layers(ffgpu_exec *ex, unsigned long long *host_out, int cap);
+
 /* Mean device time per layer KIND over the last profiled forward, in micro-
  * seconds, indexed by LAYER_TYPE_* (counterpart of ENABLE_NET_PROFILE,
  * ffcnn.c:33,494-510).  Runs one eager forward with hipEvents around each step. */
