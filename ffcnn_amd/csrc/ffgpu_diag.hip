@@ -203,6 +203,23 @@ extern "C" float ffgpu_membench(void *d_dst, const void *d_src, size_t bytes, in
 // ---- the slot tables of the split-bf16 expand GEMM (ffgpu_x3_terms.h), readable from the host: tests/test_x3_tables.py checks that
 // every partial product (weight part i, input part j, channel pair) with i + j <= 2 occurs exactly once and nothing else does
 #include "ffgpu_x3_terms.h"
+// Clock probe: one wave that does nothing but read the constant 100 MHz counter (s_memrealtime) and the shader-clock counter (s_memtime) `samples`
+// times, `gap` sleep units apart.  Launched on its own stream beside a workload it reports the shader clock the chip HOLDS under that workload
+// (the issue-bound model of the full net has to be priced at that clock, not at the 2.4 GHz of the peak table).
+__global__ void k_clock_probe(unsigned long long *out, int samples, int gap)
+{
+    for (int i = 0; i < samples; i++) {
+        const unsigned long long rt = __builtin_amdgcn_s_memrealtime(), st = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0) { out[2 * i] = rt; out[2 * i + 1] = st; }
+        for (int g = 0; g < gap; g++) __builtin_amdgcn_s_sleep(127);
+    }
+}
+extern "C" int ffgpu_clock_probe(unsigned long long *d_out, int samples, int gap, void *stream)
+{
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, d_out, samples, gap);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 extern "C" int ffgpu_diag_x3_term(int ks1, int m, int d, int out[3])
 {
     if ((ks1 != 2 && ks1 != 4 && ks1 != 6 && ks1 != 12) || m < 0 || m >= irbw_x3_nm(ks1) || d < 0 || d > 3) return -1;

@@ -567,7 +567,7 @@ int ffgpu_launch_pool(const float *in, float *out, int N, int c, int w, int h, i
 {
     if (stride < 1 || fs < 1) { ffgpu_set_error("pool: bad size/stride"); return -1; }
     const long planes = (long)N * c, total = planes * (h / stride) * (w / stride);
-    if (is_max && fs == 2 && stride == 2 && w % 8 == 0 && h % 2 == 0 && total < (1L << 32) && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0 && !getenv("FFGPU_NO_POOL2X2")) {
+    if (is_max && fs == 2 && stride == 2 && w % 8 == 0 && h % 2 == 0 && total < (1L << 32) && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0 && !env_int("FFGPU_NO_POOL2X2", 0)) {
         const unsigned owq = (unsigned)(w / 8), nquads = (unsigned)(total / 4);
         const unsigned m = owq == 1 ? 0u : (unsigned)(((1ULL << 32) + owq - 1) / owq);
         if ((unsigned long long)nquads * owq < (1ULL << 32))         // (umulhi division exact)

@@ -32,6 +32,9 @@ float ffgpu_pipe_probe2(int mode, int ns, int blocks, int iters, void *stream);
  * of MFMAs per (strip, pixel) or -1.  ffgpu_diag_xl_op: which 16-byte window of the LDS image MFMA m of the 48-channel form reads. */
 int ffgpu_diag_x3_term(int ks1, int m, int d, int out[3]);
 int ffgpu_diag_xl_op(int m);
+/* Clock probe: one wave writes `samples` pairs (s_memrealtime: constant 100 MHz, s_memtime: shader clock) into d_out (2 x samples u64), `gap` x ~8 k cycles of
+ * s_sleep apart.  On its own stream beside a workload: the shader clock the chip holds under it = d(s_memtime) / d(s_memrealtime) x 100 MHz. */
+int ffgpu_clock_probe(unsigned long long *d_out, int samples, int gap, void *stream);
 
 
 #ifdef __cplusplus

@@ -1,3 +1,2 @@
-mkdir -p gpurun_out/r5c
-python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "pw_x3t" 2>&1 | tail -3
-python tools/pw_x3t_bench.py one > gpurun_out/r5c/x3t_bench2.txt 2>&1; cat gpurun_out/r5c/x3t_bench2.txt
+mkdir -p gpurun_out/r5d
+bash tools/ab_bench.sh 3 400 libffcnn_hip.so libffcnn_hip.so:FFGPU_FRONT_BAND=20 libffcnn_hip.so:FFGPU_FRONT_BAND=32 libffcnn_hip.so:FFGPU_THIN_BAND=20 libffcnn_hip.so:FFGPU_FRONT_BAND=20,FFGPU_THIN_BAND=20 libffcnn_hip.so:FFGPU_FRONT_BAND=8 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r5d/ab_bands.txt | tail -8
