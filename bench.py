@@ -490,6 +490,8 @@ def main():
                     help="what a step starts from, resident in HBM: u8 = 64 u8 BGR 320x320 images per GPU (SURVEY 8(d) row 4; the first kernel converts "
                          "them with net_input's arithmetic, ffcnn.c:259-289) -- the default since round 4; f32 = frames already converted to planar "
                          "fp32 (rounds 1-3's headline; reported beside the value either way)")
+    ap.add_argument("--no-strong-extra", action="store_true", help="multi-GPU (or --force-gather) weak-scaling runs: skip the untimed strong_b256 extra (north_star's batch-256 job, "
+                    "merged and one step per launch, on the same ranks)")
     ap.add_argument("--no-node-line", action="store_true", help="skip the extra c_node_api measurement (a child `bench.py --node` run by rank 0 after the timed job)")
     args = ap.parse_args()
 
@@ -914,6 +916,34 @@ def main():
     for e in exs:
         e.close()
     exs = []
+    if gather_mode and not strong and not args.no_strong_extra and 256 % world == 0:
+        # ONE driver command, both scaling answers: beside the weak-scaling headline (64 frames per GPU) the same ranks run
+        # north_star's strong-scaling job -- every step is the SAME 256 frames, rank r takes shard_range(256, r, N) -- merged (as many consecutive
+        # steps' shards per launch as make ~128 frames) and with one step per launch.  Untimed extra: own executors, inputs, warm-up, K timed steps,
+        # every rank takes part (the gather is collective); `value` above is never replaced by it.
+        xs = x = J = None
+        torch.cuda.empty_cache()
+        keep = (B, lo, G)
+        G = 256
+        lo, hi = ffdist.shard_range(G, rank, world)
+        B = hi - lo
+        MSs = max(1, 128 // B)
+        sb = {"global_batch": G, "frames_per_gpu": B, "n_gpus": world, "rccl_ranks": rccl_ranks, "unit": "frames/s", "steps": args.steps,
+              "what": "untimed extra: BASELINE config[4] / north_star's batch-256 job on the same %d rank(s), shards of %d frames; "
+                      "merged = %d consecutive steps' shards per launch, unmerged = one step per launch" % (world, B, MSs)}
+        for key, ms_ in (("merged", MSs), ("unmerged", 1)):
+            if key == "unmerged" and MSs == 1:
+                sb[key] = dict(sb["merged"])
+                continue
+            Jx = job(ms_, False)
+            sb[key] = {"value": round(G * args.steps / Jx["dt"], 1), "ms_per_step": round(Jx["dt"] / args.steps * 1e3, 4), "steps_per_launch": ms_, "frames_per_launch": Jx["Bx"]}
+            for e in Jx["exs"]:
+                e.close()
+            Jx = None
+            torch.cuda.empty_cache()
+        B, lo, G = keep
+        if out is not None:
+            out["strong_b256"] = sb
     if world == 1 and not gather_mode and not args.no_extras:
         # the same job from the OTHER input format, measured exactly like the value (own executors and inputs, same warm-up, K timed steps):
         # rounds 1-3 reported fp32-resident frames; since round 4 the value starts from the u8 images SURVEY 8(d) row 4 names
@@ -952,6 +982,11 @@ def main():
         xs = x = J = None
         torch.cuda.empty_cache()
         out["c_node_api"] = node_line(args, world)
+        if world > 1 and not strong and not args.no_strong_extra and 256 % world == 0:      # ... and its batch-256 job (RCCL branch of the C node path, merged steps)
+            import copy
+            a256 = copy.copy(args)
+            a256.global_batch, a256.merge_steps = 256, 0
+            out["c_node_api_b256"] = node_line(a256, world)
     if out is not None:
         # the ONE JSON line is the last thing on stdout: RCCL's version banner sits in the C library's stdout buffer
         # until it is flushed

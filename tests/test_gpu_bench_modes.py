@@ -64,13 +64,20 @@ def test_bench_gather_step_under_torchrun():
              "--master-port", "29541", "bench.py", "--gpus", "1", "--force-gather"] + COMMON + NO_NODE)
     check_line(d, "weak", 64)
     assert "RCCL gather" in d["config"]["gather"]
+    # one command, both scaling answers: the weak-scaling line carries north_star's batch-256 job (merged and one step per launch) as an extra,
+    # with the size of the communicator it ran on
+    sb = d["strong_b256"]
+    assert sb["global_batch"] == 256 and sb["frames_per_gpu"] == 256 and sb["n_gpus"] == 1 and sb["rccl_ranks"] == 1 and d["rccl_ranks"] == 1
+    for key in ("merged", "unmerged"):
+        assert sb[key]["value"] > 0 and sb[key]["steps_per_launch"] >= 1 and abs(sb[key]["value"] - 256 * 8 / (sb[key]["ms_per_step"] * 8e-3)) / sb[key]["value"] < 1e-3
+    assert sb["unmerged"]["steps_per_launch"] == 1 and sb["merged"]["frames_per_launch"] == 256
 
 
 @pytest.mark.gpu
 def test_bench_strong_scaling_job():
     d = run([sys.executable, "bench.py", "--force-gather", "--global-batch", "256"] + COMMON + NO_NODE, port=29543)
     check_line(d, "strong", 256)
-    assert d["config"]["frames_per_gpu"] == 256
+    assert d["config"]["frames_per_gpu"] == 256 and "strong_b256" not in d      # (the extra belongs to the weak-scaling line)
 
 
 @pytest.mark.gpu

@@ -371,3 +371,53 @@ def test_first_conv_with_8_channels_keeps_one_graph(env, tmp_path):
         os.environ.pop("FFGPU_IGX3_MIN_WGS", None)
         os.environ.pop("FFGPU_IGX3_MIN_IC", None)
     o.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- grouped layers in one grid
+@pytest.mark.parametrize("batch,split", [(3, 0), (16, 0), (2, 3)])
+def test_group3_cfg_against_the_oracle(env, tmp_path, batch, split, monkeypatch):
+    """tests/data/group3.cfg (ResNeXt-shaped: grouped 3x3 layers with 4 .. 64 channels per group; what tools/other_nets.py times at 416x416) at 96 x 64:
+    every layer and the boxes against the oracle.  The grouped layers with >= 8 channels per group run on k_conv_igemm with ALL groups in one grid
+    (conv-v0.c:46-51 / conv-v6.c:505-517), also with a forced split-K (partial sums per group); the 4-channel groups on k_conv_thin"""
+    from conftest import ROOT
+    from test_gpu_parity import _write_random_weights
+    capi, torch, orc = env
+    if split:
+        monkeypatch.setenv("FFGPU_IGEMM_SPLIT", str(split))
+    txt = open(os.path.join(ROOT, "tests", "data", "group3.cfg")).read().replace("width=416", "width=96").replace("height=416", "height=64")
+    cfg = str(tmp_path / "group3_small.cfg")
+    open(cfg, "w").write(txt)
+    o = orc.Oracle(cfg=cfg, weights=None)
+    wpath = str(tmp_path / "group3.weights")
+    _write_random_weights(wpath, o, 31)
+    o.close()
+    o = orc.Oracle(cfg=cfg, weights=wpath)
+    rng = np.random.default_rng(32)
+    frames = rng.uniform(0, 1, (batch, 3, 64, 96)).astype(np.float32)
+    with capi.Net(cfg, wpath) as n:
+        names = [capi.kernel_name(batch, L.w, L.h, L.c, L.groups, L.pad, L.stride, L.fs, L.fn) for L in (n.layer(i) for i in range(n.layer_num)) if L.type == 0 and L.groups > 1]
+        assert "conv_igemm" in names and "conv_thin" in names, names
+        for flags in (capi.FFGPU.KEEP_ALL | capi.FFGPU.NO_FUSE, capi.FFGPU.KEEP_ALL, capi.FFGPU.KEEP_ALL | capi.FFGPU.NO_GRAPH):
+            with n.executor(batch, flags) as ex:
+                ex.set_scale(1, 1)
+                for rep in range(2):
+                    ex.forward_host(frames)
+                for f in sorted({0, batch // 2, batch - 1}):
+                    o.input[...] = frames[f]
+                    o.n.s1, o.n.s2 = 1, 1
+                    o.forward(0)
+                    seen = 0
+                    for i in range(o.nlayers):
+                        ref = o.layer_out(i)
+                        if ref is None:
+                            continue
+                        try:
+                            a = ex.read_layer(i, f)
+                        except RuntimeError as err:
+                            assert "not materialised" in str(err)
+                            continue
+                        seen += 1
+                        close(a, ref, "group3 flags %d frame %d layer %d" % (flags, f, i))
+                    assert seen >= 10
+                    assert abs(len(ex.read_boxes(f)) - len(o.boxes)) <= max(1, len(o.boxes) // 50)
+    o.close()

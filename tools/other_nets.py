@@ -74,6 +74,13 @@ def rows(torch, capi, table=False, tmpdir="/tmp"):
         r.append(rate(torch, capi, cfgd, wd, 416, 416, steps=40, table=table))
     finally:
         os.unlink(wd)
+    cfgg = os.path.join(ROOT, "tests", "data", "group3.cfg")                 # ResNeXt-shaped: grouped 3x3 layers (4 .. 64 channels per group), all groups of a layer in one grid
+    wg = os.path.join(tmpdir, "group3_bench_%d.weights" % os.getpid())
+    write_random_weights(capi, cfgg, wg, 416, 416)
+    try:
+        r.append(rate(torch, capi, cfgg, wg, 416, 416, steps=40, table=table))
+    finally:
+        os.unlink(wg)
     r.append(rate(torch, capi, capi.CFG, capi.WEIGHTS, 640, 448, table=table))
     return r
 
