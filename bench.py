@@ -916,8 +916,9 @@ def main():
     for e in exs:
         e.close()
     exs = []
-    if gather_mode and not strong and not args.no_strong_extra and 256 % world == 0:
-        # ONE driver command, both scaling answers: beside the weak-scaling headline (64 frames per GPU) the same ranks run
+    if (gather_mode or not args.no_extras) and not strong and not args.no_strong_extra and 256 % world == 0:
+        # ONE driver command, both scaling answers: beside the weak-scaling headline (64 frames per GPU) the same ranks -- at N = 1
+        # the one GPU, whose figure is the denominator of north_star's ">= 7.5 x at 8 GPUs vs 1 GPU on batch 256" -- run
         # north_star's strong-scaling job -- every step is the SAME 256 frames, rank r takes shard_range(256, r, N) -- merged (as many consecutive
         # steps' shards per launch as make ~128 frames) and with one step per launch.  Untimed extra: own executors, inputs, warm-up, K timed steps,
         # every rank takes part (the gather is collective); `value` above is never replaced by it.

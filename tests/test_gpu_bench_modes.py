@@ -40,6 +40,7 @@ def test_bench_default_step():
     check_line(d, "weak", 64)
     assert d["config"]["untimed_forwards_before_t0"] > 0
     # beside it: the same job through the C node API (a child `bench.py --node`), same metric, boxes checked there as well
+    assert "strong_b256" not in d                                # (--no-extras; the driver's default N = 1 line carries it: test_bench_default_line_has_strong_b256)
     c = d["c_node_api"]
     assert "error" not in c, c
     assert c["unit"] == "frames/s" and c["value"] > 0 and c["n_gpus"] == 1 and "C node API" in c["host"]
@@ -106,3 +107,12 @@ def test_bench_strong_scaling_reports_both_schedules():
     u = d["strong_unmerged"]
     assert u["steps_per_launch"] == 1 and u["frames_per_launch"] == 32 and u["value"] > 0
     assert d["rccl_ranks"] == 1                                  # --force-gather: a one-rank communicator really exists
+
+
+@pytest.mark.gpu
+def test_bench_default_line_has_strong_b256():
+    """the N = 1 line without --no-extras: the batch-256 job (the denominator of north_star's 8-vs-1 sentence) sits beside the value, as it does at N > 1"""
+    d = run([sys.executable, "bench.py", "--steps", "8", "--warmup", "4", "--no-cpu-baseline", "--no-kernel-roofline", "--no-node-line"])
+    check_line(d, "weak", 64)
+    sb = d["strong_b256"]
+    assert sb["global_batch"] == 256 and sb["frames_per_gpu"] == 256 and sb["n_gpus"] == 1 and sb["merged"]["value"] > 0 and sb["merged"]["frames_per_launch"] == 256

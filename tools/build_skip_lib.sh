@@ -5,7 +5,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 rm -rf /tmp/skipbuild && mkdir -p /tmp/skipbuild/ffcnn_amd
-cp -r $R/ffcnn_amd/csrc /tmp/skipbuild/ffcnn_amd/csrc && cp -r $R/include /tmp/skipbuild/include
+cp -r $R/ffcnn_amd/csrc /tmp/skipbuild/ffcnn_amd/csrc && cp -r $R/include /tmp/skipbuild/include && mkdir -p /tmp/skipbuild/tools && cp $R/tools/isa_lint.py /tmp/skipbuild/tools/
 rm -rf /tmp/skipbuild/ffcnn_amd/csrc/build
 make -C /tmp/skipbuild/ffcnn_amd/csrc DIAG=1 ../lib/libffcnn_hip.so > /tmp/skipbuild/make.log 2>&1 || { tail -20 /tmp/skipbuild/make.log; exit 1; }
 mkdir -p $R/tools/lab/lib
