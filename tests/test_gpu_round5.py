@@ -421,3 +421,43 @@ def test_group3_cfg_against_the_oracle(env, tmp_path, batch, split, monkeypatch)
                     assert seen >= 10
                     assert abs(len(ex.read_boxes(f)) - len(o.boxes)) <= max(1, len(o.boxes) // 50)
     o.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- k_front: three columns per lane, the seam
+@pytest.mark.parametrize("nc", [3, 4])
+@pytest.mark.parametrize("w,h", [(320, 64), (160, 64), (192, 96), (352, 32), (384, 32), (256, 32), (224, 32)])
+def test_front_kernel_columns_per_lane(env, nc, w, h, monkeypatch):
+    """k_front (layers 0-3 in one kernel) with three output columns per lane (round 5: 54 of 64 lanes on a 160-pixel row) and with four, at widths whose last lane
+    slides left by 2 / 1 / 0 columns (first-layer widths 160, 80, 96, 176, 192, 128, 112): layer 3 -- the kernel's output -- and later layers of every frame
+    against the oracle, from fp32 frames and from u8 BGR frames of the net's geometry (the u8 form realigns 18 bytes per lane that start 0 or 2 bytes into a dword)"""
+    capi, torch, orc = env
+    monkeypatch.setenv("FFGPU_FRONT_MIN_PX", "1")
+    monkeypatch.setenv("FFGPU_FRONT_NC", str(nc))
+    batch = 12                                                        # (>= 11 frames: the plan starts with k_front)
+    rng = np.random.default_rng(w * 7 + h)
+    u8 = rng.integers(0, 256, (batch, h, 3 * w), dtype=np.uint8)
+    o = orc.Oracle(w=w, h=h)
+    with capi.Net(capi.CFG, capi.WEIGHTS, w, h) as net:
+        with net.executor(batch, capi.FFGPU.KEEP_ALL) as ex:
+            ex.set_scale(1, 1)
+            d8 = torch.from_numpy(u8).cuda()
+            for mode in ("u8", "f32"):
+                fr = None
+                if mode == "u8":
+                    ex.forward_bgr_dev(d8.data_ptr(), w, h)
+                else:
+                    fr = np.zeros((batch, 3, h, w), np.float32)
+                    for f in range(batch):
+                        o.set_input_image(np.ascontiguousarray(u8[f]), w, h)
+                        fr[f] = o.input
+                    ex.forward_host(fr)
+                torch.cuda.synchronize()
+                with pytest.raises(RuntimeError, match="not materialised"):
+                    ex.read_layer(0, 0)                               # the plan really runs k_front
+                for f in (0, 5, batch - 1):
+                    o.set_input_image(np.ascontiguousarray(u8[f]), w, h)
+                    o.n.s1, o.n.s2 = 1, 1
+                    o.forward(0)
+                    for i in (3, 8, 11, 21):
+                        close(ex.read_layer(i, f), o.layer_out(i), "front nc %d %dx%d %s frame %d layer %d" % (nc, w, h, mode, f, i))
+    o.close()

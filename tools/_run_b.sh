@@ -1,1 +1,1 @@
-bash tools/ab_bench.sh 2 400 libffcnn_hip.so libffcnn_hip.so:FFGPU_BRANCH=1 2>&1 | grep -v amdgpu.ids | tail -3
+python -m pytest tests/test_gpu_round5.py -m gpu -x -q -k "front_kernel_columns" 2>&1 | tail -6

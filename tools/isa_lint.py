@@ -17,26 +17,27 @@ import sys
 CAP = 1.6       # a known form may grow to CAP x its recorded count (+ 16) before the lint asks for a fresh look
 # signature -> count at the time the form was last soaked (tools/isa_lint.py <listing> --census prints today's table)
 KNOWN_FORMS = {
-    # (operand kinds: v = VGPR pair, s = SGPR pair, c = constant / literal)
+    # (operand kinds: v = VGPR pair, s = SGPR pair, c = constant / literal; counts of the round-5 tree incl. the three-column k_front, whose u8 conversion
+    #  brought the two `vs ... op_sel:[0,1]` forms: mean / norm out of the high half of an SGPR pair -- soaked by the u8 mode of tests/test_gpu_round5.py)
     'v_pk_add_f32 vc op_sel_hi:[1,0]': 3,
-    'v_pk_add_f32 vs neg_hi:[0,1] neg_lo:[0,1]': 33,
-    'v_pk_add_f32 vs neg_hi:[0,1] neg_lo:[0,1] op_sel_hi:[1,0]': 24,
+    'v_pk_add_f32 vs neg_hi:[0,1] neg_lo:[0,1]': 69,
+    'v_pk_add_f32 vs neg_hi:[0,1] neg_lo:[0,1] op_sel_hi:[1,0]': 51,
     'v_pk_add_f32 vv neg_hi:[0,1] neg_lo:[0,1]': 7,
     'v_pk_fma_f32 vsc op_sel_hi:[1,1,0]': 40,
     'v_pk_fma_f32 vvc op_sel:[0,1,0] op_sel_hi:[1,1,0]': 8,
-    'v_pk_fma_f32 vvc op_sel:[1,0,0] op_sel_hi:[1,1,0]': 48,
-    'v_pk_fma_f32 vvc op_sel_hi:[0,1,0]': 24,
-    'v_pk_fma_f32 vvc op_sel_hi:[1,0,0]': 242,
-    'v_pk_fma_f32 vvc op_sel_hi:[1,1,0]': 692,
+    'v_pk_fma_f32 vvc op_sel:[1,0,0] op_sel_hi:[1,1,0]': 72,
+    'v_pk_fma_f32 vvc op_sel_hi:[0,1,0]': 48,
+    'v_pk_fma_f32 vvc op_sel_hi:[1,0,0]': 302,
+    'v_pk_fma_f32 vvc op_sel_hi:[1,1,0]': 790,
     'v_pk_fma_f32 vvv op_sel:[0,1,0]': 212,
-    'v_pk_fma_f32 vvv op_sel:[1,0,0]': 1152,
-    'v_pk_fma_f32 vvv op_sel_hi:[0,1,1]': 3437,
-    'v_pk_fma_f32 vvv op_sel_hi:[1,0,1]': 2164,
-    'v_pk_mul_f32 sv op_sel:[1,0]': 323,
-    'v_pk_mul_f32 sv op_sel_hi:[0,1]': 263,
+    'v_pk_fma_f32 vvv op_sel:[1,0,0]': 1992,
+    'v_pk_fma_f32 vvv op_sel_hi:[0,1,1]': 4781,
+    'v_pk_fma_f32 vvv op_sel_hi:[1,0,1]': 2608,
+    'v_pk_mul_f32 sv op_sel:[1,0]': 51,
+    'v_pk_mul_f32 sv op_sel_hi:[0,1]': 349,
     'v_pk_mul_f32 vc op_sel_hi:[1,0]': 1,
-    'v_pk_mul_f32 vs op_sel_hi:[1,0]': 118,
-    'v_pk_mul_f32 vv op_sel:[1,0]': 144,
+    'v_pk_mul_f32 vs op_sel_hi:[1,0]': 143,
+    'v_pk_mul_f32 vv op_sel:[1,0]': 216,
     'v_pk_mul_f32 vv op_sel_hi:[0,1]': 144,
 }
 
