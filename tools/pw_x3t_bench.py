@@ -10,7 +10,7 @@ if len(sys.argv) > 1 and sys.argv[1] in ("one", "pmc"):
     SHAPES = SHAPES[:1]
 s = torch.cuda.Stream()
 FORCE = {"FFGPU_PWX3T_MIN_IC": "8", "FFGPU_PWX3T_MIN_OC": "8", "FFGPU_PWX3T_MIN_P": "1"}
-VARIANTS = [("x3t", dict(FORCE, FFGPU_PW_X3T="1")), ("x3t no narrow", dict(FORCE, FFGPU_PW_X3T="1", FFGPU_PWXT_NARROW="0")), ("x3t no epilogue", dict(FORCE, FFGPU_PW_X3T="1", FFGPU_PWXT_DBG="2")),
+VARIANTS = [("x3t", dict(FORCE, FFGPU_PW_X3T="1")), ("x3t persistent", dict(FORCE, FFGPU_PW_X3T="1", FFGPU_PWXT_PERSIST="1")), ("x3t no narrow", dict(FORCE, FFGPU_PW_X3T="1", FFGPU_PWXT_NARROW="0")), ("x3t no epilogue", dict(FORCE, FFGPU_PW_X3T="1", FFGPU_PWXT_DBG="2")),
             ("x3s", {"FFGPU_PW_X3T": "0", "FFGPU_PWX3S_MIN_OC": "8", "FFGPU_PWX3S_MIN_IC": "8", "FFGPU_PWX3S_MIN_WGS": "1"}), ("pw_x3", {"FFGPU_PW_X3T": "0", "FFGPU_PW_X3S": "0", "FFGPU_PWX3_MIN_IC": "8", "FFGPU_PWX3_MIN_OC": "8", "FFGPU_PWX3_MIN_P": "1"}),
             ("fp32", {"FFGPU_PW_X3T": "0", "FFGPU_PW_X3S": "0", "FFGPU_PW_X3": "0"})]
 if len(sys.argv) > 1 and sys.argv[1] == "pmc":
