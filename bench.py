@@ -551,6 +551,7 @@ def main():
     prios = [int(v) for v in os.environ.get("FFCNN_BENCH_STREAM_PRIORITY", "-1").split(",")]      # (a list: chain j takes prios[j % len])
     prio = prios[0]
     stream = torch.cuda.Stream(priority=prio)
+    chain_streams = [stream]
     net = capi.Net()
     # weights: rank 0's folded filter rows -> every GPU over RCCL (one-off, outside the timed region)
     wptr, wbytes = net.weights_dev()
@@ -593,7 +594,12 @@ def main():
         if S >= 3:
             flags |= capi.FFGPU.CONCURRENT      # plan for throughput: several chains fill the device together
         exs = [net.executor(Bx, flags) for _ in range(S)]
-        streams = [stream] + [torch.cuda.Stream(priority=prios[j % len(prios)]) for j in range(1, S)]
+        # the chain streams are made ONCE per process and every job of this run (the value, the strong_b256 and other-input extras) uses the same
+        # ones: a fourth set of fresh priority streams lands two chains on one hardware queue (the fp32 extra read 150 k instead of 203 k behind
+        # the two strong_b256 jobs; profiles/r05_b, r05_c)
+        while len(chain_streams) < S:
+            chain_streams.append(torch.cuda.Stream(priority=prios[len(chain_streams) % len(prios)]))
+        streams = chain_streams[:S]
         ex = exs[0]
         model_bytes, model_flops = ex.work_model()
 

@@ -12,8 +12,8 @@ R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 bash tools/profile_round4.sh $TAG
 timeout 300 python tools/pw_x3t_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_pw_x3t.txt
-FFGPU_PWX3T_MIN_IC=8 timeout 600 bash tools/pmc.sh k_pw_x3t "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" \
+FFGPU_PWX3T_MIN_IC=8 timeout 600 bash tools/pmc.sh "k_pw_x3t<" "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" \
     "SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
-    -- python $R/tools/pw_x3t_bench.py pmc 2>&1 | grep "k_pw_x3t \|GFLOP" > gpurun_out/${TAG}_pw_x3t_pmc.txt
+    -- python $R/tools/pw_x3t_bench.py pmc 2>&1 | grep "k_pw_x3t<\|GFLOP" > gpurun_out/${TAG}_pw_x3t_pmc.txt
 timeout 300 python tools/clock_mix.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_clock_mix.txt
 cat gpurun_out/${TAG}_clock_mix.txt
