@@ -10,6 +10,8 @@ import pytest
 
 from test_gpu_kernels import make_filter
 
+YOLO_KIND = 7                                                   # LAYER_TYPE_YOLO (include/ffcnn.h:45)
+
 
 @pytest.fixture(scope="module")
 def env():
@@ -106,6 +108,46 @@ def test_conv_x3_back_to_back(env, shape):
 
 # ---- dense 3x3 layers on the split form (ffgpu_conv_x3.inc) inside a PLANNED net: plan-time image, MT frozen in the plan, fused shortcut,
 # ragged widths (52 -> 26 -> 13), maxpool / route / upsample around them -- a darknet-tiny-style backbone
+def boxes_match_up_to_threshold_flips(got, want, thresholds, what):
+    """the boxes of a darknet-style cfg against the oracle's, by class, score (1e-4) and corners (0.05), in the reference's score order (ffcnn.c:301).
+    A box may be missing on either side only if its score lies within 1e-4 of a yolo layer's ignore_thres (ffcnn.c:259-289 keeps `conf >= thres` and stores conf
+    as the score: a conf within rounding of the threshold flips between two fp32 orders of the same dot product).  Such a box has the lowest score of its frame,
+    so it suppresses nothing above it in the NMS.  At most 2 % of a frame's boxes (one at least) may flip.
+    Corners: 0.05 pixel + 1e-4 of the box's own scale.  The sizes are exp(t) x anchor (ffcnn.c:259-289), so a difference d in the yolo layer's input t is a
+    RELATIVE d in the size; with random weights these cfgs produce boxes up to 3e7 pixels tall, where the 1e-5 of the yolo-fastest helpers cannot hold:
+    measured on dark3.cfg (tools/diag_boxes.py) the yolo inputs sit within 5.9e-5 of the oracle's (the layer check admits 1e-3), every box has its partner at
+    the same place with the score within 1.3e-6 and the corners within a relative 4.1e-5."""
+    def scale(b):
+        return max(abs(float(b["x2"]) - float(b["x1"])), abs(float(b["y2"]) - float(b["y1"])), max(abs(float(b[c])) for c in ("x1", "y1", "x2", "y2")))
+    used = np.zeros(len(got), bool)
+    pairs, lost = [], []
+    for k, w in enumerate(want):
+        hit = -1
+        for j in range(len(got)):
+            g = got[j]
+            if (not used[j] and int(g["type"]) == int(w["type"]) and abs(float(g["score"]) - float(w["score"])) <= 1e-4 and
+                    all(abs(float(g[c]) - float(w[c])) <= 0.05 + 1e-4 * scale(w) for c in ("x1", "y1", "x2", "y2"))):
+                hit = j
+                break
+        if hit < 0:
+            lost.append(("oracle", k, w))
+        else:
+            used[hit] = True
+            pairs.append((k, hit))
+    lost += [("hip", j, got[j]) for j in range(len(got)) if not used[j]]
+    for side, k, b in lost:
+        assert min(abs(float(b["score"]) - t) for t in thresholds) <= 1e-4, "%s: %s box %d %r has no counterpart and is not at a threshold %r" % (what, side, k, b, thresholds)
+    assert len(lost) <= max(1, len(want) // 50), "%s: %d boxes flipped at the threshold (%d reference boxes)" % (what, len(lost), len(want))
+    for (k0, j0), (k1, j1) in zip(pairs, pairs[1:]):              # same order, except between scores an ulp apart
+        assert j1 > j0 or abs(float(want[k1]["score"]) - float(want[k0]["score"])) <= 2e-6, "%s: boxes %d / %d change places across a real score gap" % (what, k0, k1)
+
+
+def _yolo_thresholds(n):
+    t = sorted(set(round(float(L.ignore_thres), 6) for L in (n.layer(i) for i in range(n.layer_num)) if L.type == YOLO_KIND))
+    assert t, "no yolo layer"
+    return t
+
+
 def _c(filters, size, stride, act, bn=1):
     return "[convolutional]\n%sfilters=%d\nsize=%d\nstride=%d\npad=1\nactivation=%s\n\n" % ("batch_normalize=1\n" if bn else "", filters, size, stride, act)
 
@@ -174,8 +216,7 @@ def test_conv_x3_layers_in_an_executor(env, tmp_path, batch, which, monkeypatch)
                         seen += 1
                         close(a, ref, "dense3 cfg flags %d frame %d layer %d" % (flags, f, i))
                     assert seen >= 8 or not (flags & capi.FFGPU.KEEP_ALL)
-                    got, want = ex.read_boxes(f), o.boxes
-                    assert abs(len(got) - len(want)) <= max(1, len(want) // 50), (flags, f, len(got), len(want))      # (a score within rounding of the threshold may flip)
+                    boxes_match_up_to_threshold_flips(ex.read_boxes(f), o.boxes, _yolo_thresholds(n), "dense3 cfg %s flags %d frame %d" % (which, flags, f))
     o.close()
 
 
@@ -222,7 +263,7 @@ def test_dark3_cfg_against_the_oracle(env, tmp_path, batch, force, monkeypatch):
         o.input[...] = frames[f]
         o.n.s1, o.n.s2 = 1, 1
         o.forward(0)
-        refs.append(({i: o.layer_out(i).copy() for i in range(o.nlayers) if o.layer_out(i) is not None}, len(o.boxes)))
+        refs.append(({i: o.layer_out(i).copy() for i in range(o.nlayers) if o.layer_out(i) is not None}, o.boxes.copy()))
     with capi.Net(cfg, wpath) as n:
         assert n.layer_num == o.nlayers
         if force:
@@ -241,5 +282,5 @@ def test_dark3_cfg_against_the_oracle(env, tmp_path, batch, force, monkeypatch):
                                 assert "not materialised" in str(e)
                                 continue
                             close(a, ref, "dark3 flags %d frame %d layer %d" % (flags, f, i))
-                    assert abs(len(ex.read_boxes(f)) - refs[f][1]) <= max(1, refs[f][1] // 50), (flags, f)
+                    boxes_match_up_to_threshold_flips(ex.read_boxes(f), refs[f][1], _yolo_thresholds(n), "dark3 flags %d frame %d" % (flags, f))
     o.close()
