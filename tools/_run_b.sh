@@ -1,1 +1,3 @@
-python -m pytest tests/test_gpu_round5.py -q -m gpu -k "group3" 2>&1 | tail -12
+export FFCNN_HIP_LIB=$PWD/tools/lab/lib/libffcnn_hip_trace.so
+IRB_TRACE_CONCURRENT=1 python tools/irb_trace.py 2>&1 | grep "trace\|^irbw" | cut -c1-400 > gpurun_out/irb_trace_conc.txt
+cat gpurun_out/irb_trace_conc.txt | tail -40
