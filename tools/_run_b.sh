@@ -1,3 +1,2 @@
-export FFCNN_HIP_LIB=$PWD/tools/lab/lib/libffcnn_hip_trace.so
-IRB_TRACE_CONCURRENT=1 python tools/irb_trace.py 2>&1 | grep "trace\|^irbw" | cut -c1-400 > gpurun_out/irb_trace_conc.txt
-cat gpurun_out/irb_trace_conc.txt | tail -40
+python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" 2>&1 | grep -v amdgpu.ids | tail -2
+python -m pytest tests -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -15
