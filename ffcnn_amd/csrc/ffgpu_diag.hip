@@ -148,6 +148,85 @@ extern "C" float ffgpu_pipe_probe2(int mode, int ns, int blocks, int iters, void
     return ms * 1000.f / 2;
 }
 
+// ---- the same question for the BF16 matrix cores (round 5): do v_mfma_f32_16x16x32_bf16 and vector-ALU work overlap -- inside a wave, between the
+// waves of a SIMD?  MODE 0: 16 x MFMA; 2: 16 x (MFMA, NS/2 v_pk_fma_f32); 4: the packed FMAs alone; 5: waves 0-3 of the workgroup run MODE 0's
+// stream, waves 4-7 MODE 4's (cross-wave overlap: two waves of different kinds per SIMD at 8 waves per workgroup); 6: as 5 with the fp32 MFMA.
+template <int MODE, int NS>
+__global__ void __launch_bounds__(512) k_pipe_probe3(float *out, int iters)
+{
+    typedef float pv4 __attribute__((ext_vector_type(4)));
+    typedef float pv2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 pb8 __attribute__((ext_vector_type(8)));
+    typedef unsigned pu4 __attribute__((ext_vector_type(4)));
+    pv4 acc[16];
+    pv2 w[4];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = (pv4){ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = (pv2){ (float)threadIdx.x + i, 1.f };
+    const float a = 1.0f + threadIdx.x * 1e-6f, b = 0.999f;
+    const pv2 b2 = { b, b }, a2 = { a, a };
+    const unsigned h = 0x3f803f80u ^ (threadIdx.x * 0x00010001u & 0x007f007fu);
+    const pb8 A8 = __builtin_bit_cast(pb8, (pu4){ h, h ^ 0x00110022u, h ^ 0x00330044u, h ^ 0x00550066u }), B8 = __builtin_bit_cast(pb8, (pu4){ h ^ 0x00010001u, h, h ^ 0x00070003u, h });
+    // (waves 0-3 / 4-7 of a 512-thread workgroup: one of each kind per SIMD; the role is a scalar and decided ONCE, outside the loops)
+    const int role = (MODE == 5 || MODE == 6) ? (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) & 1) : 0;
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (MODE == 6) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(A8), "v"(B8));
+        }
+    };
+    auto pks = [&]() {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+#pragma unroll
+            for (int j = 0; j < NS / 2; j++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(w[(i * (NS / 2) + j) & 3]) : "v"(b2), "v"(a2));
+    };
+    if (MODE == 0) { for (int it = 0; it < iters; it++) mfmas(); }
+    else if (MODE == 4) { for (int it = 0; it < iters; it++) pks(); }
+    else if (MODE == 2) {
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(A8), "v"(B8));
+#pragma unroll
+                for (int j = 0; j < NS / 2; j++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(w[(i * (NS / 2) + j) & 3]) : "v"(b2), "v"(a2));
+            }
+        }
+    } else if (role == 0) { for (int it = 0; it < iters; it++) mfmas(); }
+    else { for (int it = 0; it < iters; it++) pks(); }
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r += w[i].x + w[i].y;
+    if (r == 12345.678f) out[threadIdx.x] = r;
+}
+
+extern "C" float ffgpu_pipe_probe3(int mode, int ns, int blocks, int threads, int iters, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    static float *d_out = nullptr;
+    if (!d_out && hipMalloc(&d_out, 512 * sizeof(float)) != hipSuccess) return -1.f;
+    if (threads != 256 && threads != 512) { ffgpu_set_error("pipe_probe3: 256 or 512 threads"); return -1.f; }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
+    for (int rep = 0; rep < 3; rep++) {
+        if (rep == 1) (void)hipEventRecord(e0, s);
+#define PP3(M, N) if (mode == M && ns == N) hipLaunchKernelGGL((k_pipe_probe3<M, N>), dim3(blocks), dim3(threads), 0, s, d_out, iters); else
+        PP3(0, 0) PP3(2, 2) PP3(2, 4) PP3(2, 8) PP3(2, 16) PP3(4, 2) PP3(4, 4) PP3(4, 8) PP3(4, 16) PP3(5, 4) PP3(5, 8) PP3(5, 16) PP3(6, 4) PP3(6, 8) PP3(6, 16)
+        { ffgpu_set_error("pipe_probe3: unsupported mix"); return -1.f; }
+#undef PP3
+    }
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms * 1000.f / 2;
+}
+
 extern "C" float ffgpu_pipe_probe(int n_mfma, int n_valu, int blocks, int iters, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;

@@ -27,6 +27,10 @@ float ffgpu_pipe_probe(int n_mfma, int n_valu, int blocks, int iters, void *stre
 /* the same question with hand-placed instruction streams: mode 0 = 16 MFMAs per trip; 1 = each followed by `ns` plain
  * v_fma_f32; 2 = by ns/2 v_pk_fma_f32; 3 / 4 = the vector instructions alone.  Microseconds per launch. */
 float ffgpu_pipe_probe2(int mode, int ns, int blocks, int iters, void *stream);
+/* the bf16 matrix cores (v_mfma_f32_16x16x32_bf16): mode 0 = 16 MFMAs per trip; 2 = each followed by ns/2 v_pk_fma_f32; 4 = the packed FMAs alone;
+ * 5 = waves 0-3 of a 512-thread workgroup run mode 0's stream, waves 4-7 mode 4's (cross-wave overlap); 6 = as 5 with v_mfma_f32_16x16x4_f32.
+ * `threads` = 256 or 512 per workgroup.  Microseconds per launch. */
+float ffgpu_pipe_probe3(int mode, int ns, int blocks, int threads, int iters, void *stream);
 /* host only: the slot tables of the split-bf16 ("X3") expand GEMM of the fused blocks (ffcnn_amd/csrc/ffgpu_x3_terms.h): dword d of MFMA m
  * for a lane with ks1 input channels holds weight part out[0] (-1: empty), input part out[1], channel pair out[2]; returns the number
  * of MFMAs per (strip, pixel) or -1.  ffgpu_diag_xl_op: which 16-byte window of the LDS image MFMA m of the 48-channel form reads. */
