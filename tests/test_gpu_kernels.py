@@ -346,14 +346,16 @@ PW_X3T_SHAPES = [  # (ic, oc, N, H, W, act): BASELINE config[2]'s layer at a sma
 ]
 
 
-@pytest.mark.parametrize("narrow", [1, 0])
+@pytest.mark.parametrize("narrow", [1, 0, "nt"])
 @pytest.mark.parametrize("shape", PW_X3T_SHAPES)
 def test_pw_x3t(env, orc, shape, narrow, monkeypatch):
     """the TILED split-bf16 pointwise GEMM (ffgpu_pw_x3t.inc, round 5: every input value split once per 256 output channels by its workgroup, weights by
     LDS-DMA, two LDS buffers, v_mfma_f32_32x32x16_bf16): the checks of test_pw_x3 -- every fp32 kernel's tolerance against the generic kernel and the oracle,
-    and the fp32-reorder bound |d| <= 2^-20 * scale' * sum|w x| + 1 ulp; with and without the narrow tiles of the partial last round"""
+    and the fp32-reorder bound |d| <= 2^-20 * scale' * sum|w x| + 1 ulp; with and without the narrow tiles of the partial last round, and with the
+    streamed (non-temporal) output stores that outputs of 128 MB and more get by default forced on ("nt")"""
     capi, torch = env
-    monkeypatch.setenv("FFGPU_PWXT_NARROW", str(narrow))
+    monkeypatch.setenv("FFGPU_PWXT_NARROW", "0" if narrow == 0 else "1")
+    monkeypatch.setenv("FFGPU_PWXT_NT", "1" if narrow == "nt" else "0")
     ic, oc, N, H, W, act = shape
     rng = np.random.default_rng(hash(shape) & 0xffff)
     x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)

@@ -44,6 +44,20 @@ def test_lint_barrier_rule():
     assert isa_lint.check_lds_dma(k2)[0]                                                      # (conservative: any vector-memory instruction between the wait and the barrier is refused)
 
 
+def test_lint_buffer_store_rule():
+    """the pair found in round 5 (k_pw_x3t with buffer stores: element 1 of sporadic 16-byte stores wrong), and what must NOT fire"""
+    st = "\tbuffer_store_dwordx4 v[2:5], v158, s[28:31], s6 offen nt\n"
+    assert isa_lint.check_buffer_store(st + "\tv_fma_f32 v3, v115, v6, v7\n")[0]                       # the original
+    assert isa_lint.check_buffer_store(st + "\tv_pk_mul_f32 v[4:5], v[8:9], v[10:11]\n")[0]             # a register pair that overlaps the data
+    assert isa_lint.check_buffer_store(st + "\t;;#ASMSTART\n\t;;#ASMEND\n\tv_max_f32_e32 v2, v1, v2\n")[0]    # comments are not wait states
+    assert isa_lint.check_buffer_store(st + "\tv_fma_f32 v1, v131, v6, v7\n")[0] == []                  # writes something else
+    assert isa_lint.check_buffer_store(st + "\ts_nop 0\n\tv_fma_f32 v3, v115, v6, v7\n")[0] == []       # one wait state is enough
+    assert isa_lint.check_buffer_store("\tbuffer_store_dwordx4 v[2:5], v158, s[28:31], 0 offen\n\tv_fma_f32 v3, v115, v6, v7\n")[0] == []   # immediate soffset: hipcc's business
+    assert isa_lint.check_buffer_store("\tbuffer_store_dwordx2 v[2:3], v158, s[28:31], s6 offen\n\tv_fma_f32 v3, v115, v6, v7\n")[0] == []  # 8 bytes: no hazard
+    errs, facts = isa_lint.lint(st + "\tv_fma_f32 v3, v115, v6, v7\n")
+    assert errs and "SGPR soffset" in errs[0] and facts["buffer_store_hazards"] == 1
+
+
 @pytest.fixture(scope="module")
 def isa(tmp_path_factory):
     src = os.path.join(ROOT, "ffcnn_amd", "csrc")

@@ -10,7 +10,11 @@ lint fails the build) and by tests/test_isa_lint.py.      python tools/isa_lint.
     MFMAs in the round-4 / round-5 soaks (tests/test_gpu_round4.py, test_gpu_round5.py) without a differing bit.  A compiler upgrade that emits a NEW form, or
     many more of a known one (CAP x today's count), fails here instead of in the field.
 (3) Kernels that stage operands by LDS-DMA (global_load_lds_dwordx4 / buffer_load_dwordx4 ... lds): every s_barrier must be preceded by an
-    s_waitcnt vmcnt(0) with no vector-memory instruction in between -- hipcc does not model that these loads write LDS."""
+    s_waitcnt vmcnt(0) with no vector-memory instruction in between -- hipcc does not model that these loads write LDS.
+(4) No buffer_store_dwordx3 / x4 with its soffset in an SGPR may be followed DIRECTLY by a vector instruction that writes one of its data registers: on gfx950
+    that dword of the store is corrupted on some lanes (found in round 5 in a k_pw_x3t epilogue: `buffer_store_dwordx4 v[2:5], v158, s[28:31], s6 offen`
+    then `v_fma_f32 v3, ...` -- element 1 of sporadic 16-byte stores wrong, profiles/r05_e_buffer_store_hazard.txt).  hipcc's hazard recognizer inserts the
+    wait state only for an immediate soffset (and for global / flat stores, which is why the product uses those)."""
 import re
 import sys
 
@@ -115,6 +119,36 @@ def check_lds_dma(text):
     return errs, seen
 
 
+def reg_range(op):
+    """'v[2:5]' -> (2, 5), 'v3' -> (3, 3), else None"""
+    m = re.match(r"v\[(\d+):(\d+)\]$", op)
+    if m:
+        return int(m.group(1)), int(m.group(2))
+    m = re.match(r"v(\d+)$", op)
+    return (int(m.group(1)),) * 2 if m else None
+
+
+def check_buffer_store(text):
+    """rule (4): buffer_store_dwordx3 / x4 with an SGPR soffset directly followed by a vector instruction that writes one of its data registers"""
+    errs, nst = [], 0
+    lines = [l.strip() for l in text.split("\n") if l.strip() and not l.strip().startswith((";", ".", "//")) and not l.strip().endswith(":")]
+    for i, l in enumerate(lines[:-1]):
+        m = re.match(r"buffer_store_dwordx[34]\s+(v\[\d+:\d+\]),\s*(\S+),\s*(s\[\d+:\d+\]),\s*(\S+)", l)
+        if not m:
+            continue
+        nst += 1
+        if not re.match(r"s\d+$", m.group(4).rstrip(",")):            # `0`, `off`, a literal: hipcc inserts the wait state itself
+            continue
+        nxt = lines[i + 1]
+        if not nxt.startswith("v_") or nxt.startswith(("v_cmp", "v_cmpx", "v_readfirstlane", "v_readlane")):
+            continue
+        dst = reg_range(nxt.split(None, 1)[1].split(",")[0].strip()) if len(nxt.split(None, 1)) > 1 else None
+        lo, hi = reg_range(m.group(1))
+        if dst and dst[0] <= hi and dst[1] >= lo:
+            errs.append("buffer store of more than 8 bytes with an SGPR soffset, data register overwritten by the next instruction: %s | %s" % (l, nxt))
+    return errs, nst
+
+
 def lint(text):
     """list of error strings (empty = clean), and the facts the tests assert on"""
     forms, bad, npk = census(text)
@@ -127,7 +161,8 @@ def lint(text):
         elif n > KNOWN_FORMS[key] * CAP + 16:
             errs.append("packed-fp32 form grew from %d to %d instructions (re-soak, then update KNOWN_FORMS): %s" % (KNOWN_FORMS[key], n, key))
     e2, seen = check_lds_dma(text)
-    return errs + e2, {"npk": npk, "forms": forms, "lds_dma_kernels": seen}
+    e3, nst = check_buffer_store(text)
+    return errs + e2 + e3[:5], {"npk": npk, "forms": forms, "lds_dma_kernels": seen, "wide_buffer_stores": nst, "buffer_store_hazards": len(e3)}
 
 
 if __name__ == "__main__":
