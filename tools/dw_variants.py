@@ -16,7 +16,7 @@ torch.cuda.synchronize()
 s = torch.cuda.Stream(priority=-1)
 nbytes = 2 * x.numel() * 4
 capi.diag().ffgpu_membench(y.data_ptr(), x.data_ptr(), nbytes // 2, 0, 1024, 64, s.cuda_stream)
-variants = [{}, {"FFGPU_DW_BAND": "8"}, {"FFGPU_DW_BAND": "16"}, {"FFGPU_DW_NT": "1"}, {"FFGPU_DW_BAND": "8", "FFGPU_DW_NT": "1"}, {"FFGPU_DW_U": "2"}, {"FFGPU_DW_BAND": "8", "FFGPU_DW_U": "2"},
+variants = [{}, {"FFGPU_DW_NT": "0"}, {"FFGPU_DW_BAND": "8"}, {"FFGPU_DW_BAND": "16"}, {"FFGPU_DW_BAND": "8", "FFGPU_DW_NT": "0"}, {"FFGPU_DW_U": "2"}, {"FFGPU_DW_BAND": "8", "FFGPU_DW_U": "2"},
             {"FFGPU_DW_XCD": "1"}, {"FFGPU_DW_BAND": "8", "FFGPU_DW_XCD": "1"}, {"FFGPU_DW_BAND": "20"}, {"FFGPU_DW_BAND": "40"}]
 res = {i: [] for i in range(len(variants))}
 for rnd in range(4):
@@ -28,4 +28,4 @@ for rnd in range(4):
         res[i].append(us)
 for i, v in enumerate(variants):
     r = sorted(res[i])
-    print("%-48s median %.1f us  (%.3f of 8 TB/s)  runs %s" % (v or "default (band 4, U 4)", r[len(r) // 2], nbytes / r[len(r) // 2] / 1e3 / 8000, ["%.1f" % u for u in res[i]]))
+    print("%-48s median %.1f us  (%.3f of 8 TB/s)  runs %s" % (v or "default (band 4, U 4, streamed stores)", r[len(r) // 2], nbytes / r[len(r) // 2] / 1e3 / 8000, ["%.1f" % u for u in res[i]]))
