@@ -18,10 +18,10 @@ fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 
 
-def pick(d, key):
+def pick(d, key, name=False):
     for k, v in d.items():
         if key in k:
-            return v[0]
+            return k if name else v[0]
     raise SystemExit("kernel %s not in profile: %s" % (key, list(d)))
 
 
@@ -31,7 +31,8 @@ dw_r_raw = pick(fetch, "k_dw3_stream") * 1024.0
 dw_w_raw = pick(write, "k_dw3_stream") * 1024.0
 fr, fw = NBYTES / cal_r, NBYTES / cal_w           # calibration factors (guide: expect ~2.0 for reads)
 res = {
-    "kernel": "k_dw3_stream<2,4,false>", "workload": "dw3x3 s1 p1 320x320x64 batch 64 fp32",
+    "kernel": pick(fetch, "k_dw3_stream", True).replace("void ", "").replace(", ", ","),      # the instantiation that ran (<2,4,true>: streamed stores, round 5)
+     "workload": "dw3x3 s1 p1 320x320x64 batch 64 fp32",
     "algorithmic_bytes_per_launch": 2 * NBYTES,
     "raw_FETCH_SIZE_bytes": dw_r_raw, "raw_WRITE_SIZE_bytes": dw_w_raw,
     "calibration": {"copy_bytes_each_way": NBYTES, "raw_FETCH_copy": cal_r, "raw_WRITE_copy": cal_w,
