@@ -645,6 +645,31 @@ def test_irb_wave_two_strips(env, shape, tile, monkeypatch):
     test_irb_fused_block(env, shape)
 
 
+@pytest.mark.parametrize("shape", [(8, 32, 8, 1, 7, 80, 80, True), (16, 96, 16, 1, 5, 40, 40, True), (24, 136, 24, 1, 11, 20, 20, True), (48, 224, 48, 1, 13, 10, 10, True),
+                                   (4, 24, 8, 2, 3, 160, 160, False), (16, 96, 24, 2, 9, 40, 40, False)])
+def test_irb_wave_tile_order(env, shape, monkeypatch):
+    """the fused blocks walk their tiles XCD by XCD (irbw_xcd_block, round 5): workgroup counts that are no multiple of 8, one-wave-per-tile and group-split
+    launches -- against the oracle (every tile computed exactly once), and bit for bit the same as in workgroup-id order (a tile's arithmetic does not depend on who runs it)"""
+    capi, torch = env
+    ic, ec, oc, stride, N, H, W, use_res = shape
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f1, fd, f2 = make_filter(rng, ec, ic), make_filter(rng, ec, 9), make_filter(rng, oc, ec)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = rng.uniform(-1, 1, (oc * N, OH, OW)).astype(np.float32)
+    t = [torch.from_numpy(a).cuda() for a in (x, f1, fd, f2, res)]
+    outs = []
+    for order in ("0", "3"):
+        monkeypatch.setenv("FFGPU_IRBW_XCD", order)
+        out = torch.full((oc * N, OH, OW), float("nan"), device="cuda")
+        capi.irb_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr() if use_res else None, out.data_ptr(), N, W, H, ic, ec, oc, stride)
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    assert not np.isnan(outs[1]).any() and np.array_equal(outs[0], outs[1])
+    monkeypatch.setenv("FFGPU_IRBW_XCD", "3")
+    test_irb_fused_block(env, shape)
+
+
 @pytest.mark.parametrize("G", [1, 2, 3, 5, 8])
 @pytest.mark.parametrize("shape", [(24, 136, 24, 1, 3, 20, 20, True), (48, 224, 48, 1, 2, 10, 10, True), (8, 48, 16, 1, 2, 40, 40, False),
                                    (4, 24, 8, 2, 2, 48, 32, True)])
