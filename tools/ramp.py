@@ -8,7 +8,7 @@ os.environ.setdefault("FFGPU_BRANCH", "0")
 S, K = 4, int(sys.argv[1]) if len(sys.argv) > 1 else 24
 net = capi.Net()
 exs = [net.executor(64, capi.FFGPU.HOST_DETS | capi.FFGPU.CONCURRENT) for _ in range(S)]
-sts = [torch.cuda.Stream() for _ in range(S)]
+sts = [torch.cuda.Stream(priority=int(os.environ["RAMP_PRIO"])) if "RAMP_PRIO" in os.environ else torch.cuda.Stream() for _ in range(S)]       # RAMP_PRIO=-1: bench.py's chain streams
 xs = [torch.rand((64, 3, 320, 320), device="cuda") for _ in range(8)]
 for rep in range(3):
     for i in range(8):
