@@ -462,3 +462,67 @@ def test_front_kernel_columns_per_lane(env, nc, w, h, monkeypatch):
                     for i in (3, 8, 11, 21):
                         close(ex.read_layer(i, f), o.layer_out(i), "front nc %d %dx%d %s frame %d layer %d" % (nc, w, h, mode, f, i))
     o.close()
+
+
+# ---- the two kernels that stream their output past the caches (round 5, late): back to back, against the ORACLE, run to run bit for bit.
+# (The store-data hazard of DESIGN 5.12 (b) showed as element 1 of sporadic 16-byte stores; one launch of one shape caught it by luck.)
+@pytest.mark.parametrize("nt", ["0", "1"])
+@pytest.mark.parametrize("shape", [(256, 512, 64, 20, 20), (64, 256, 164, 20, 20), (120, 255, 64, 20, 20), (72, 300, 83, 20, 20)])
+def test_pw_x3t_back_to_back_against_the_oracle(env, shape, nt, monkeypatch):
+    """k_pw_x3t, plain and streamed (non-temporal) output stores: 3 x 20 launches back to back into NaN-filled outputs; sampled frames of the last launch of every
+    repetition against the oracle (tolerance of every fp32 kernel), the repetitions bit for bit equal to each other"""
+    capi, torch, orc = env
+    monkeypatch.setenv("FFGPU_PWXT_NT", nt)
+    ic, oc, N, H, W = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    f = make_filter(rng, oc, ic)
+    f[:, :ic] *= 3.0 / np.sqrt(ic)
+    assert capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc, capi.FFGPU.K_PW_X3T) == "pw_x3t"
+    dx, df = torch.from_numpy(x).cuda(), torch.from_numpy(f).cuda()
+    xf = x.reshape(ic, N, H, W)
+    frames = sorted({0, N // 3, N - 1})
+    refs = {n: orc.groupconv(np.ascontiguousarray(xf[:, n]), f, 1, 0, 1, 1, 2) for n in frames}
+    first = None
+    for rep in range(3):
+        y = torch.full((oc * N, H, W), float("nan"), device="cuda")
+        capi.groupconv_time_dev(dx.data_ptr(), df.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2, variant=capi.FFGPU.K_PW_X3T, warmup=0, iters=20)
+        torch.cuda.synchronize()
+        got = y.cpu().numpy().reshape(oc, N, H, W)
+        for n in frames:
+            close(got[:, n], refs[n], "pw_x3t %s nt=%s rep %d frame %d" % (shape, nt, rep, n))
+        assert not np.isnan(got).any()
+        if first is None:
+            first = got
+        else:
+            assert np.array_equal(got, first), "rep %d differs from rep 0 in %d outputs" % (rep, int((got != first).sum()))
+
+
+@pytest.mark.parametrize("nt", ["0", "1"])
+@pytest.mark.parametrize("shape", [(64, 16, 320, 320), (24, 8, 160, 160), (7, 5, 37, 44)])
+def test_dw3_stream_back_to_back_against_the_oracle(env, shape, nt, monkeypatch):
+    """k_dw3_stream, cached and streamed (stores + band-private rows non-temporal): 3 x 20 launches back to back, sampled planes against the oracle, repetitions bit for bit"""
+    capi, torch, orc = env
+    monkeypatch.setenv("FFGPU_DW_NT", nt)
+    C, N, H, W = shape
+    rng = np.random.default_rng(hash(shape) & 0xffff)
+    x = rng.uniform(-1, 1, (C * N, H, W)).astype(np.float32)
+    f = make_filter(rng, C, 9)
+    assert capi.kernel_name(N, W, H, C, C, 1, 1, 3, C) == "dw3_stream"
+    dx, df = torch.from_numpy(x).cuda(), torch.from_numpy(f).cuda()
+    xf = x.reshape(C, N, H, W)
+    frames = sorted({0, N // 2, N - 1})
+    refs = {n: orc.groupconv(np.ascontiguousarray(xf[:, n]), f, C, 1, 1, 3, 2) for n in frames}
+    first = None
+    for rep in range(3):
+        y = torch.full((C * N, H, W), float("nan"), device="cuda")
+        capi.groupconv_time_dev(dx.data_ptr(), df.data_ptr(), y.data_ptr(), N, W, H, C, C, 1, 1, 3, C, act=2, warmup=0, iters=20)
+        torch.cuda.synchronize()
+        got = y.cpu().numpy().reshape(C, N, H, W)
+        for n in frames:
+            close(got[:, n], refs[n], "dw3_stream %s nt=%s rep %d frame %d" % (shape, nt, rep, n))
+        assert not np.isnan(got).any()
+        if first is None:
+            first = got
+        else:
+            assert np.array_equal(got, first)

@@ -24,7 +24,12 @@ for rep in range(int(os.environ.get('REPS', '6'))):
             with torch.cuda.stream(sts[j]):
                 torch.cuda._sleep(int((S - 1 - j) * al * 1e-6 * 2.4e9))
     h0 = time.perf_counter()
+    syn = int(os.environ.get("SYNC_ROUNDS", "0"))             # 1: a chain starts round r only when every chain has finished round r - 1 (events between the chains)
     for i in range(K):
+        if syn and i >= S and (i // S) % syn == 0:
+            for k in range(S):
+                if k != i % S:
+                    sts[i % S].wait_event(evs[(i // S - 1) * S + k])
         exs[i % S].forward_dev(xs[i % 8].data_ptr(), sts[i % S].cuda_stream)
         host.append((time.perf_counter() - h0) * 1e3)
         e = torch.cuda.Event(enable_timing=True); e.record(sts[i % S]); evs.append(e)
