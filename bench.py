@@ -176,10 +176,15 @@ def cpu_baseline(secs=8.0):
     v4 = "v4_fast_v3"
     if {"avx2", "fma", "bmi2"} <= cpu_flags() and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libffcnn_ref_%s.so" % v4)):
         try:
-            env = dict(os.environ, OMP_NUM_THREADS=str(ncore), OMP_PROC_BIND="close", OMP_PLACES="cores")
+            # 8 threads, not one per core: conv-v4's only parallel region is one output-channel loop of a few microseconds, so every further thread
+            # adds barrier time and nothing else (OMP_NUM_THREADS = 128 on the EPYC 9575F box: 1.3-2.1 frames/s in rounds 4 / 5 -- an over-subscription
+            # artefact of the reference's pragma, not a property of the host; VERDICT r05 nit)
+            nomp = min(ncore, 8)
+            env = dict(os.environ, OMP_NUM_THREADS=str(nomp), OMP_PROC_BIND="close", OMP_PLACES="cores")
             r4, f4 = run([-1], var=v4, env=env)
-            out["openmp_v4"] = {"value": round(r4, 3), "unit": "frames/s", "cores": ncore, "threads": ncore,
-                                "how": "reference ffcnn.c+conv-v4.c (-Ofast -march=x86-64-v3 -fopenmp), one process, OMP_NUM_THREADS=%d, %d frames" % (ncore, f4)}
+            out["openmp_v4"] = {"value": round(r4, 3), "unit": "frames/s", "cores": nomp, "threads": nomp,
+                                "how": "reference ffcnn.c+conv-v4.c (-Ofast -march=x86-64-v3 -fopenmp), one process, OMP_NUM_THREADS=%d (capped: the pragma's parallel "
+                                       "region is a microsecond-sized channel loop, one thread per core of %d only adds barrier time), %d frames" % (nomp, ncore, f4)}
         except Exception as e:                                  # noqa: BLE001 -- an extra
             out["openmp_v4"] = {"error": repr(e)[:200]}
     return out
@@ -689,8 +694,10 @@ def main():
                     host[g][:, :nb].copy_(big[:, :nb], non_blocking=True)   # one D2H copy for the whole job's records of the group
                 ev_comm[g].record(comm)
 
-        def step(i):
+        def step(i, rev=False):
             j = i % S                                               # executor / stream of this step
+            if rev:
+                j = S - 1 - j                                       # (value_repeats: the chain that is otherwise enqueued last goes first)
             if not gather_mode:                                     # in-order streams: no events, no copies
                 fwd(exs[j], xs[i % K_in], streams[j])
                 shipped["group"] = j
@@ -775,7 +782,19 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         assert [e.graph_captures for e in exs] == caps0, "a graph was captured inside the timed region"
-        return dict(fwd=fwd, exs=exs, streams=streams, xs=xs, x=x, ex=ex, model_bytes=model_bytes, model_flops=model_flops, dt=dt, untimed=untimed, shipped=shipped, host=host, pbytes=pbytes, roof=roof, roof_pw=roof_pw, check=check, K_in=K_in, S=S, M=M, Bx=Bx, flags=flags, host_dets=host_dets, gather_mode=gather_mode)
+        # value_repeats: the SAME K-step region five more times, back to back behind the value (untimed extras, `value` is the first
+        # region and nothing else).  A 20-step region is 6.5 ms; DESIGN.md section 7 found one region in ten 7 % slower because the chain that was
+        # enqueued last falls out of lockstep in its first round -- on the odd repeats that chain is enqueued FIRST, which tests the explanation.
+        reps = []
+        if world == 1 and not gather_mode and with_roofline:
+            for r in range(5):
+                fence()
+                t1 = time.perf_counter()
+                for i in range(nl):
+                    step(i, rev=bool(r & 1))
+                fence()
+                reps.append(time.perf_counter() - t1)
+        return dict(reps=reps, fwd=fwd, exs=exs, streams=streams, xs=xs, x=x, ex=ex, model_bytes=model_bytes, model_flops=model_flops, dt=dt, untimed=untimed, shipped=shipped, host=host, pbytes=pbytes, roof=roof, roof_pw=roof_pw, check=check, K_in=K_in, S=S, M=M, Bx=Bx, flags=flags, host_dets=host_dets, gather_mode=gather_mode)
 
     J = job(MS, True)
     exs = J["exs"]
@@ -851,7 +870,7 @@ def main():
                        "launches_per_step": ex.kernel_count, "arena_MB": round(ex.arena_bytes / 2**20, 1),
                        "executors": S, "pipelining": "%d executors on %d streams take the batches in turn%s" % (S, S, ", each split in two half-batch chains" if args.split else ""), "gather": ("RCCL gather of %d steps' records (packed: %d bytes per step and rank) + D2H on a side stream, overlapped with the next steps" % (M, pbytes)) if gather_mode else "records written to pinned host memory by the NMS kernel",
                        "graph_captures_per_executor": max(e.graph_captures for e in exs),     # (one per input format used: the u8 form of the first kernel has its own graph)
-                       "weights": "data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL, untimed)",
+                       "weights": ("data/yolo-fastest-1.1.weights (broadcast from rank 0 over RCCL to %d ranks, untimed)" % rccl_ranks) if world > 1 else "data/yolo-fastest-1.1.weights (one GPU: loaded by net_load, no broadcast)",
                        "boxes_match_reference_golden_frame0": ok,
                        "boxes_match_reference_golden_frame0_every_chain": ok_all},
             # the whole net against the two ceilings that exist for it (per GPU): what the FUSED launch list must move
@@ -864,6 +883,14 @@ def main():
                              "mfma_f32_frac": round(model_flops / MS / per_gpu_s / 1e12 / FP32_MFMA_PEAK_TF, 4),
                              "batch": B},
         }
+        if J["reps"]:
+            rv = [G * args.steps / t for t in J["reps"]]
+            srt = sorted(rv)
+            out["value_repeats"] = {"n": len(rv), "unit": "frames/s", "min": round(srt[0], 1), "median": round(srt[len(srt) // 2], 1), "max": round(srt[-1], 1),
+                                    "values": [round(v, 1) for v in rv], "median_over_value": round(srt[len(srt) // 2] / fps, 4),
+                                    "order": ["chains enqueued 0..%d" % (S - 1) if not (r & 1) else "last chain first" for r in range(len(rv))],
+                                    "what": "untimed extras: the same %d-step region %d more times back to back behind `value` (which is the FIRST region only); "
+                                            "on the odd repeats the chain that is otherwise enqueued last goes first (DESIGN.md section 7)" % (args.steps, len(rv))}
         if roof is not None:
             out["roofline"] = roof
             out["roofline_pw"] = roof_pw

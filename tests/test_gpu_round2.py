@@ -25,6 +25,14 @@ def close(a, ref, what=""):
     assert err.max() <= 0, "%s: max excess %.3g (max |d| %.3g)" % (what, err.max(), np.abs(a - ref).max())
 
 
+def close_dev(a, b, what=""):
+    """two DEVICE tensors, every element, the same tolerance (no host copy of 0.2 - 1.7 GB)"""
+    import torch
+    assert not torch.isnan(a).any() and not torch.isnan(b).any(), what + ": unwritten outputs"
+    err = (a - b).abs() - (ATOL + RTOL * b.abs())
+    assert float(err.max()) <= 0, "%s: max excess %.3g (max |d| %.3g)" % (what, float(err.max()), float((a - b).abs().max()))
+
+
 def boxes_match(got, want, what=""):
     assert len(got) == len(want), "%s: %d vs %d boxes" % (what, len(got), len(want))
     for k, (g, w) in enumerate(zip(got, want)):
@@ -96,6 +104,15 @@ def test_pw_config2_against_oracle(F, orc, variant, N, sample):
     for n in sample:
         ref = orc.groupconv(np.ascontiguousarray(x[:, n]), f, 1, 0, 1, 1, act)
         close(dy[:, n].cpu().numpy(), ref, "%s N=%d frame %d" % (variant, N, n))
+    # 100 % of the outputs: the whole tensor against a SECOND device path that the lines above / below tie to the oracle on the
+    # same sampled frames -- the one-thread-per-output kernel (conv-v0.c:7-31's k-ordered chain) -- within the fp32 tolerance
+    d2 = torch.full((oc, N, H, W), float("nan"), device="cuda")
+    F.groupconv_dev(dx.data_ptr(), df.data_ptr(), d2.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act, 0, F.FFGPU.K_GENERIC, None)
+    torch.cuda.synchronize()
+    for n in sample[:2]:
+        ref = orc.groupconv(np.ascontiguousarray(x[:, n]), f, 1, 0, 1, 1, act)
+        close(d2[:, n].cpu().numpy(), ref, "K_GENERIC N=%d frame %d" % (N, n))
+    close_dev(dy, d2, "%s N=%d whole tensor vs K_GENERIC" % (variant, N))
 
 
 def test_dw_config1_full_batch_sampled(F, orc):
@@ -113,9 +130,36 @@ def test_dw_config1_full_batch_sampled(F, orc):
     torch.cuda.synchronize()
     assert F.kernel_name(N, W, H, C_, C_, 1, 1, 3, C_) == "dw3_stream"
     assert not torch.isnan(y).any()
-    for c, n in ((0, 0), (63, 63), (17, 40), (32, 1), (5, 62)):
+    # planes: first / last task of the grid, and both sides of every place where k_dw3_stream<2,4,true>'s index arithmetic changes:
+    # the XCD remap hands plane ranges of 4096 / 8 = 512 (c N + n) to each XCD -> planes 511 | 512, 2047 | 2048, 3583 | 3584
+    planes = [(0, 0), (63, 63), (17, 40), (32, 1), (5, 62)] + [divmod(q, N) for q in (511, 512, 2047, 2048, 3583, 3584)]
+    for c, n in planes:
         ref = orc.groupconv(x[c:c + 1, n].cpu().numpy(), f[c:c + 1], 1, 1, 1, 3, 2)
         close(y[c, n].cpu().numpy()[None], ref, "dw config[1] plane (%d, %d)" % (c, n))
+    # 100 % of the outputs: the whole tensor against two other device paths (whole planes staged in LDS; one thread per output), each tied to the
+    # oracle on sampled planes here -- a depthwise output is one 9-term fmaf chain in the reference's tap order in all three: they agree to the last bit
+    for other in ("K_DW_LDS", "K_GENERIC"):
+        y2 = torch.full((C_, N, H, W), float("nan"), device="cuda")
+        F.groupconv_dev(x.data_ptr(), df.data_ptr(), y2.data_ptr(), N, W, H, C_, C_, 1, 1, 3, C_, 2, 0, getattr(F.FFGPU, other), None)
+        torch.cuda.synchronize()
+        for c, n in planes[:3]:
+            ref = orc.groupconv(x[c:c + 1, n].cpu().numpy(), f[c:c + 1], 1, 1, 1, 3, 2)
+            close(y2[c, n].cpu().numpy()[None], ref, "%s plane (%d, %d)" % (other, c, n))
+        close_dev(y, y2, "dw config[1] whole tensor vs %s" % other)
+        del y2
+    # the lane-63 / lane-0 seam of the two 16-byte vectors per lane (columns 255 | 256) and the 4-row band seams (rows 4 k - 1 | 4 k): an impulse
+    # response through the product kernel puts every tap of plane 0 where the oracle puts it
+    imp = torch.zeros((1, 1, H, W), device="cuda")
+    for (r, q) in ((3, 255), (4, 256), (163, 252), (316, 259), (319, 0), (0, 319)):
+        imp[0, 0, r, q] = 1.0 + 0.25 * r / H
+    xi = torch.zeros((C_, N, H, W), device="cuda")
+    xi[:] = imp
+    yi = torch.full((C_, N, H, W), float("nan"), device="cuda")
+    F.groupconv_dev(xi.data_ptr(), df.data_ptr(), yi.data_ptr(), N, W, H, C_, C_, 1, 1, 3, C_, 2, 0, F.FFGPU.K_AUTO, None)
+    torch.cuda.synchronize()
+    for c, n in ((0, 0), (63, 63), (31, 63), (32, 0)):
+        ref = orc.groupconv(imp[0].cpu().numpy(), f[c:c + 1], 1, 1, 1, 3, 2)
+        close(yi[c, n].cpu().numpy()[None], ref, "dw config[1] impulses, plane (%d, %d)" % (c, n))
 
 
 # ------------------------------------------------------------------ batch-32 / batch-64 plans, activations
