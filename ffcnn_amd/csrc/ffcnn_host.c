@@ -131,11 +131,27 @@ static int split_ints(char *v, int *dst, int cap)
 /* ------------------------------------------------------------------------ */
 static int filter_row_len(const LAYER *l) { return UP(l->fs * l->fs * (l->c / l->groups), 4) + 4; }
 
-static void shape_layers(NET *net, const char *cfg, int inputw, int inputh)
+/* Limits on what a cfg may ask for.  The reference computes all of this in int without a check (ffcnn.c:139-171: a route or shortcut
+ * index outside the net reads / writes beside layer_list, sizes overflow silently); here a cfg outside the limits makes net_load fail
+ * with a message.  Every limit is far beyond any darknet cfg: tensors and the weight buffer must fit an int count of floats. */
+#define FF_MAX_DIM   65536
+#define FF_MAX_CH    (1 << 20)
+#define FF_MAX_FLOATS 0x7fffffffLL
+
+static int tensor_ok(const LAYER *t)
+{
+    return t->w >= 1 && t->h >= 1 && t->c >= 1 && t->w <= FF_MAX_DIM && t->h <= FF_MAX_DIM && t->c <= FF_MAX_CH &&
+           (long long)t->w * t->h * t->c <= FF_MAX_FLOATS;
+}
+
+/* 0, or -1 with the error text set */
+static int shape_layers(NET *net, const char *cfg, int inputw, int inputh)
 {
     cfg_sec s;
     int cur = 0;
     char val[256];
+    long long wsize = 0;
+    if (inputw < 0 || inputh < 0 || inputw > FF_MAX_DIM || inputh > FF_MAX_DIM) { ffgpu_set_error("net_load: input size %d x %d", inputw, inputh); return -1; }
     for (const char *p = cfg; (p = next_section(p, &s)) != NULL; ) {
         if (sec_is(&s, "net")) {
             LAYER *l0 = net->layer_list;
@@ -147,6 +163,12 @@ static void shape_layers(NET *net, const char *cfg, int inputw, int inputh)
         int kind = layer_kind(&s);
         if (kind < 0 || cur >= net->layer_num) continue;
         LAYER *in = net->layer_list + cur, *out = in + 1;
+        if (!tensor_ok(in)) {                                  /* (a head leaves its output zeroed: only a route may follow it) */
+            if (!(kind == LAYER_TYPE_ROUTE && cur > 0 && in[-1].type == LAYER_TYPE_YOLO)) {
+                ffgpu_set_error("net_load: layer %d has an input of %d x %d x %d", cur, in->w, in->h, in->c);
+                return -1;
+            }
+        }
         in->type = kind; in->stride = 1; in->groups = 1;
         switch (kind) {
         case LAYER_TYPE_CONV: {
@@ -158,28 +180,38 @@ static void shape_layers(NET *net, const char *cfg, int inputw, int inputh)
             in->pad = sec_num(&s, "pad") ? in->fs / 2 : 0;
             in->batchnorm = sec_num(&s, "batch_normalize") != 0;
             in->activation = activation_id(sec_str(&s, "activation", val, sizeof val));
+            if (in->fn < 1 || in->fn > FF_MAX_CH || in->fs < 1 || in->fs > 1024 || in->stride < 1 || in->stride > FF_MAX_DIM || in->groups < 1 ||
+                in->fs > in->w + 2 * in->pad || in->fs > in->h + 2 * in->pad || (long long)in->fs * in->fs * (in->c / in->groups) > FF_MAX_FLOATS / 8) {
+                ffgpu_set_error("net_load: conv layer %d: filters %d size %d stride %d groups %d on %d x %d x %d", cur, in->fn, in->fs, in->stride, in->groups, in->w, in->h, in->c);
+                return -1;
+            }
             out->c = in->fn;
             out->w = (in->w + 2 * in->pad - in->fs) / in->stride + 1;
             out->h = (in->h + 2 * in->pad - in->fs) / in->stride + 1;
-            net->weight_size += in->fn * filter_row_len(in);
+            wsize += (long long)in->fn * filter_row_len(in);
+            if (wsize > FF_MAX_FLOATS) { ffgpu_set_error("net_load: more than 2^31 weights at layer %d", cur); return -1; }
             break; }
         case LAYER_TYPE_AVGPOOL: case LAYER_TYPE_MAXPOOL: {
             int v;
             in->fs = sec_num(&s, "size");
             if ((v = sec_num(&s, "stride")) != 0) in->stride = v;
+            if (in->stride < 1 || in->fs < 0 || in->fs > FF_MAX_DIM) { ffgpu_set_error("net_load: pool layer %d: size %d stride %d", cur, in->fs, in->stride); return -1; }
             out->c = in->c; out->w = in->w / in->stride; out->h = in->h / in->stride;
             break; }
         case LAYER_TYPE_UPSAMPLE: {
             int v;
             if ((v = sec_num(&s, "stride")) != 0) in->stride = v;
+            if (in->stride < 1 || (long long)in->w * in->stride > FF_MAX_DIM || (long long)in->h * in->stride > FF_MAX_DIM) { ffgpu_set_error("net_load: upsample layer %d: stride %d", cur, in->stride); return -1; }
             out->c = in->c; out->w = in->w * in->stride; out->h = in->h * in->stride;
             break; }
-        case LAYER_TYPE_SHORTCUT:
-            in->depend_list[0] = sec_num(&s, "from") + cur;
+        case LAYER_TYPE_SHORTCUT: {
+            const long long d = (long long)sec_num(&s, "from") + cur;
+            if (d < 0 || d >= cur) { ffgpu_set_error("net_load: shortcut layer %d: from = layer %lld", cur, d); return -1; }
+            in->depend_list[0] = (int)d;
             in->depend_num = 1;
             in->activation = activation_id(sec_str(&s, "activation", val, sizeof val));
             out->c = in->c; out->w = in->w; out->h = in->h;
-            break;
+            break; }
         case LAYER_TYPE_DROPOUT:
             out->c = in->c; out->w = in->w; out->h = in->h;
             break;
@@ -187,9 +219,11 @@ static void shape_layers(NET *net, const char *cfg, int inputw, int inputh)
             int ids[4];
             int n = split_ints((char *)sec_str(&s, "layers", val, sizeof val), ids, 4);
             for (int k = 0; k < n; k++) {
-                int d = ids[k] > 0 ? ids[k] : cur + ids[k];
+                const long long d = ids[k] > 0 ? (long long)ids[k] : (long long)cur + ids[k];
+                if (d < 0 || d >= cur) { ffgpu_set_error("net_load: route layer %d: source layer %lld", cur, d); return -1; }
                 const LAYER *src = net->layer_list + d + 1;     /* OUTPUT of layer d */
-                in->depend_list[k] = d;
+                in->depend_list[k] = (int)d;
+                if ((long long)out->c + src->c > FF_MAX_CH) { ffgpu_set_error("net_load: route layer %d: too many channels", cur); return -1; }
                 out->c += src->c; out->w = src->w; out->h = src->h;
             }
             in->depend_num = n;
@@ -211,6 +245,9 @@ static void shape_layers(NET *net, const char *cfg, int inputw, int inputh)
         }
         cur++;
     }
+    if (!tensor_ok(net->layer_list)) { ffgpu_set_error("net_load: empty or oversized input geometry %d x %d x %d", net->layer_list->w, net->layer_list->h, net->layer_list->c); return -1; }
+    net->weight_size = (int)wsize;
+    return 0;
 }
 
 static int count_layers(const char *cfg)
@@ -270,8 +307,9 @@ NET *net_load(char *cfg_path, char *weights_path, int inputw, int inputh)
     if (!net) { free(cfg); return NULL; }
     net->layer_list = (LAYER *)(net + 1);
     net->layer_num = nl;
-    shape_layers(net, cfg, inputw, inputh);
+    const int shaped = shape_layers(net, cfg, inputw, inputh);
     free(cfg);
+    if (shaped != 0) { free(net); return NULL; }               /* (nothing but the block itself exists yet) */
 
     ffcnn_ext *ext = (ffcnn_ext *)(net->layer_list + nl + 1);
     ext->magic = FFCNN_EXT_MAGIC;
