@@ -68,7 +68,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_node_input_dev", "ffgpu_node_input_slot_dev", "ffgpu_node_depth", "ffgpu_node_rccl_ranks", "ffgpu_node_forward", "ffgpu_node_forward_host",
            "ffgpu_node_submit", "ffgpu_node_wait", "ffgpu_node_run"]
 # include/ffcnn_hip_diag.h (libffcnn_hip_diag.so: lab equipment, its own library)
-DIAG_EXPORTS = ["ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_pipe_probe2", "ffgpu_pipe_probe3", "ffgpu_diag_x3_term", "ffgpu_diag_xl_op", "ffgpu_clock_probe"]
+DIAG_EXPORTS = ["ffgpu_membench", "ffgpu_pipe_probe", "ffgpu_pipe_probe2", "ffgpu_pipe_probe3", "ffgpu_mfma_floor", "ffgpu_diag_x3_term", "ffgpu_diag_xl_op", "ffgpu_clock_probe"]
 
 
 def library_path():
@@ -199,6 +199,8 @@ def diag():
         D.ffgpu_pipe_probe3.restype = C.c_float
         D.ffgpu_pipe_probe3.argtypes = [i, i, i, i, i, vp]
         D.ffgpu_clock_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        D.ffgpu_mfma_floor.restype = C.c_float
+        D.ffgpu_mfma_floor.argtypes = [vp, i, i, i, vp]
         _diag = D
     return _diag
 

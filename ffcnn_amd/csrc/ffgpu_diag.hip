@@ -227,6 +227,68 @@ extern "C" float ffgpu_pipe_probe3(int mode, int ns, int blocks, int threads, in
     return ms * 1000.f / 2;
 }
 
+// ---- MFMA-only floor of BASELINE config[2]'s split-bf16 GEMM (round 6): the 48-MFMA chunk pattern of k_pw_x3t (ffgpu_pw_x3t.inc:
+// v_mfma_f32_32x32x16_bf16, 2 x 4 accumulators = 128 registers, six weight and twelve input fragments per chunk) with NOTHING else -- no loads, no split,
+// no LDS, no barrier, no stores; the fragments are read once from `frag` ([18][256] x 16 bytes: real split operands, so the matrix cores toggle the way
+// they do in the kernel).  Wrong results by construction: it is the time the chip needs for the launch's MFMAs alone at the clock its power limit grants.
+__global__ void __launch_bounds__(256, 2) k_mfma_floor(const uint4 *frag, float *out, int trips)
+{
+    typedef __bf16 fb8 __attribute__((ext_vector_type(8)));
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    fb8 fa[2][3], fb[4][3];
+#pragma unroll
+    for (int i = 0; i < 6; i++) fa[i / 3][i % 3] = __builtin_bit_cast(fb8, frag[i * 256 + threadIdx.x]);
+#pragma unroll
+    for (int i = 0; i < 12; i++) fb[i / 3][i % 3] = __builtin_bit_cast(fb8, frag[(6 + i) * 256 + threadIdx.x]);
+    f16v acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[r][j][e] = 0.f;
+    constexpr int WP[6] = { 0, 1, 2, 0, 1, 0 }, XP[6] = { 2, 1, 0, 1, 0, 0 };
+    for (int t = 0; t < trips; t++) {
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2)
+#pragma unroll
+            for (int m = 0; m < 6; m++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                    for (int r = 0; r < 2; r++)
+                        acc[r][jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[r][WP[m]], fb[jp + jj][XP[m]], acc[r][jp + jj], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 6; i++) asm volatile("" : "+v"(fa[i / 3][i % 3]));          // (the operands stay opaque: nothing is hoisted or folded across trips)
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) s += acc[r][j][e];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+extern "C" float ffgpu_mfma_floor(const void *d_frag, int trips, int blocks, int iters, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    static float *d_out = nullptr;
+    if (!d_out && hipMalloc(&d_out, 256 * sizeof(float)) != hipSuccess) return -1.f;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_mfma_floor, dim3(blocks), dim3(256), 0, s, (const uint4 *)d_frag, d_out, trips);     // warm-up: the clock settles under the load
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_mfma_floor, dim3(blocks), dim3(256), 0, s, (const uint4 *)d_frag, d_out, trips);
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms * 1000.f / iters;
+}
+
 extern "C" float ffgpu_pipe_probe(int n_mfma, int n_valu, int blocks, int iters, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;

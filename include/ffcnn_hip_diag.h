@@ -31,6 +31,10 @@ float ffgpu_pipe_probe2(int mode, int ns, int blocks, int iters, void *stream);
  * 5 = waves 0-3 of a 512-thread workgroup run mode 0's stream, waves 4-7 mode 4's (cross-wave overlap); 6 = as 5 with v_mfma_f32_16x16x4_f32.
  * `threads` = 256 or 512 per workgroup.  Microseconds per launch. */
 float ffgpu_pipe_probe3(int mode, int ns, int blocks, int threads, int iters, void *stream);
+/* MFMA-only floor of k_pw_x3t (round 6): `blocks` x 4 waves each run `trips` x the kernel's 48-MFMA chunk pattern (v_mfma_f32_32x32x16_bf16, 128 accumulator
+ * registers) on the 18 fragments in d_frag ([18][256] x 16 bytes) and nothing else; microseconds per launch after `iters` warm-up launches.  Wrong results by
+ * construction -- it prices the launch's MFMAs alone at the clock the power limit grants (tools/mfma_floor.py). */
+float ffgpu_mfma_floor(const void *d_frag, int trips, int blocks, int iters, void *stream);
 /* host only: the slot tables of the split-bf16 ("X3") expand GEMM of the fused blocks (ffcnn_amd/csrc/ffgpu_x3_terms.h): dword d of MFMA m
  * for a lane with ks1 input channels holds weight part out[0] (-1: empty), input part out[1], channel pair out[2]; returns the number
  * of MFMAs per (strip, pixel) or -1.  ffgpu_diag_xl_op: which 16-byte window of the LDS image MFMA m of the 48-channel form reads. */
