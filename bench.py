@@ -275,6 +275,40 @@ def pw_roofline(torch, capi, stream):
         pass
     kname = capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc)
     split = kname in ("pw_x3", "pw_x3s", "pw_x3t")
+    # beside it: the MFMA-only floor of this launch on this box -- the launch's 4 915 200 v_mfma_f32_32x32x16_bf16 in k_pw_x3t's chunk pattern
+    # on operands split from the same distributions and NOTHING else (lab kernel in libffcnn_hip_diag.so, wrong results by construction; tools/mfma_floor.py):
+    # the time the power limit grants the arithmetic alone.  `frac` stays priced against the spec peak; `frac_of_floor` says how much of the gap is the chip's.
+    floor = None
+    if kname == "pw_x3t":
+        try:
+            import numpy as np
+            D = capi.diag()
+            rng = np.random.default_rng(1)
+
+            def parts(v):
+                v = v.astype(np.float32)
+                out = []
+                for _ in range(3):
+                    t = (v.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+                    out.append((t.view(np.uint32) >> 16).astype(np.uint32))
+                    v = v - t
+                return out
+            fr = np.zeros((18, 256, 4), np.uint32)
+            wp, xp = parts(rng.uniform(-0.5, 0.5, (2, 256, 8))), parts(rng.uniform(-1, 1, (4, 256, 8)))
+            for pt in range(3):
+                for r in range(2):
+                    fr[r * 3 + pt] = wp[pt][r, :, 0::2] | (wp[pt][r, :, 1::2] << 16)
+                for j in range(4):
+                    fr[6 + j * 3 + pt] = xp[pt][j, :, 0::2] | (xp[pt][j, :, 1::2] << 16)
+            d_fr = torch.from_numpy(fr.view(np.int32)).cuda()
+            n_mfma = int(round(6 * flops / 32768))
+            us_floor = float(D.ffgpu_mfma_floor(d_fr.data_ptr(), n_mfma // (512 * 4 * 48), 512, 40, stream.cuda_stream))
+            if us_floor > 0:
+                floor = {"us_per_launch": round(us_floor, 2), "frac_of_floor": round(us_floor / us, 4), "GHz_at_full_matrix_pipe": round(n_mfma * 32 / 1024.0 / us_floor / 1e3, 3),
+                         "what": "the launch's %d bf16 MFMAs alone on this box, two workgroups per CU, 128 accumulator registers, operands of the same distributions: "
+                                 "no loads, no split, no LDS, no stores (ffgpu_mfma_floor, lab library); power-limited clock" % n_mfma}
+        except (OSError, AttributeError, RuntimeError):
+            floor = None
     note = None
     if split:
         note = ("fp32-equivalent results from split operands: every fp32 value = three exact bf16 parts, six partial products per multiply-add on the bf16 "
@@ -285,7 +319,9 @@ def pw_roofline(torch, capi, stream):
     peak = BF16_PEAK_TF / 6.0 if split else FP32_MFMA_PEAK_TF
     return {"bf16_opt_in": bf, "fp32_mfma_kernel": f32k, "bound": "mfma", "kernel": kname, "achieved": round(tfs, 2),
             "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tfs / peak, 4),
-            "frac_of_fp32_mfma_peak": round(tfs / FP32_MFMA_PEAK_TF, 4), "note": note,
+            "frac_of_fp32_mfma_peak": round(tfs / FP32_MFMA_PEAK_TF, 4), "frac_of_split_peak": round(tfs / (BF16_PEAK_TF / 6.0), 4) if split else None,
+            "frac_base": "bf16 dense peak / 6 (split kernels, since round 5; rounds 1-4: the fp32 matrix peak = `frac_of_fp32_mfma_peak`)" if split else "fp32 matrix peak",
+            "mfma_only_floor": floor, "note": note,
             "us_per_launch": round(us, 2), "dtype": "f32",
             "workload": "pw1x1 256->512 20x20 batch 256 fp32 (BASELINE config[2])"}
 

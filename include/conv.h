@@ -26,12 +26,13 @@
  * k-ordered chain (conv-v0.c:7-31) for every finite input.  The kernels AUTO
  * picks for dense 3x3 layers and large 1x1 layers compute each product from
  * three exact bf16 parts per operand on the bf16 matrix cores (24 significand
- * bits kept, fp32 accumulation: a summation ORDER, not a precision).  ONE
- * documented difference (tests/test_gpu_round5.py::test_x3_non_finite_lanes):
- * a +-Inf INPUT value makes every output whose window holds it NaN there, where
- * the reference gives +-Inf unless the Inf meets a zero tap or an opposite Inf
- * (both results are non-finite; no other output is affected).  Sub-normal
- * inputs and magnitudes spread over 2^-30 .. 2^30 in one sum behave like fp32.
+ * bits kept, fp32 accumulation: a summation ORDER, not a precision).
+ * Non-finite inputs behave as in the reference (round 6): a +-Inf input gives
+ * +-Inf with the sign of w * Inf where it meets non-zero weights, NaN where it
+ * meets a zero weight or an opposite Inf; a NaN input gives NaN; no other output
+ * is affected (tests/test_gpu_round5.py::test_x3_non_finite_lanes compares the
+ * pattern with the oracle's output by output).  Sub-normal inputs and magnitudes
+ * spread over 2^-30 .. 2^30 in one sum behave like fp32.
  */
 #ifndef FFCNN_AMD_CONV_H
 #define FFCNN_AMD_CONV_H

@@ -262,10 +262,11 @@ def test_x3_subnormal_inputs(env, variant, fs, pad, name):
 
 @pytest.mark.parametrize("variant,fs,pad,name", X3_KERNELS)
 def test_x3_non_finite_lanes(env, variant, fs, pad, name):
-    """+-Inf and NaN among the inputs.  DOCUMENTED DIFFERENCE (include/conv.h): the reference propagates +-Inf as +-Inf (or NaN where an
-    Inf meets a zero weight or an opposite Inf); the split form turns an Inf input into NaN (x - trunc(x) = Inf - Inf).  What is held: an output whose
-    receptive field holds a non-finite input is non-finite in BOTH, every other output is untouched and within the ordinary tolerance -- a non-finite
-    value never leaks into a neighbour's sum (zero-weight padding of K included)."""
+    """+-Inf and NaN among the inputs: the split form gives what the reference gives (conv-v0.c:7-31, utils.h:15-23) -- +-Inf with the sign of w * Inf where one
+    Inf meets non-zero weights, NaN where it meets a ZERO weight or an opposite Inf or where the input is NaN -- output by output (round 6, VERDICT r05 item 5: the
+    residual parts of an Inf input are zero, a zero part of a non-zero weight is packed as sign(w) 2^(e - 40); round 5 turned every Inf input into NaN).  Weights
+    that are bf16 numbers (two zero parts), weights with one zero part and zero weights on the Inf channels are in the filter on purpose.  An output whose window
+    holds no non-finite input is untouched and within the ordinary tolerance: nothing leaks into a neighbour's sum (zero-weight padding of K included)."""
     capi, torch, orc = env
     ic, oc, N, H, W = 40, 24, 2, 8, 8            # ic = 40: ragged for every k-step size (16 / 32)
     rng = np.random.default_rng(9)
@@ -275,18 +276,77 @@ def test_x3_non_finite_lanes(env, variant, fs, pad, name):
     xf[3, 0, 2, 5] = np.inf
     xf[39, 0, 6, 1] = -np.inf                    # the LAST channel: its row is the one padded k-slots re-read
     xf[17, 1, 4, 4] = np.nan
+    xf[5, 1, 1, 6] = np.inf                      # two Infs in one window, opposite signs through the weights of some outputs
+    xf[6, 1, 1, 6] = -np.inf
     f = make_filter(rng, oc, K)
+    taps = fs * fs
+    f[0, :K] = np.round(f[0, :K] * 64) / 64                      # bf16 numbers: parts 1 and 2 are zero
+    f[1, :K] = (f[1, :K].view(np.uint32) & 0xffffff00).view(np.float32)        # part 2 is zero
+    f[2, 3 * taps:4 * taps] = 0.0                                # a zero weight on the +Inf channel: 0 * Inf = NaN in the reference
+    f[3, 39 * taps:40 * taps] = 0.0                              # ... on the -Inf channel
+    f[4, 5 * taps:6 * taps] = np.abs(f[4, 5 * taps:6 * taps]) + 0.01            # Inf - Inf = NaN for this output, Inf + Inf for the next
+    f[4, 6 * taps:7 * taps] = np.abs(f[4, 6 * taps:7 * taps]) + 0.01
+    f[5, 5 * taps:6 * taps] = np.abs(f[5, 5 * taps:6 * taps]) + 0.01
+    f[5, 6 * taps:7 * taps] = -np.abs(f[5, 6 * taps:7 * taps]) - 0.01
+    f[6, :K] = np.where(rng.random(K) < 0.5, 0.0, f[6, :K])      # half of the weights zero
     got, refs, _ = _edge_case(capi, torch, orc, variant, fs, pad, x, f, ic, oc, N, H, W)
     touched = np.zeros((N, H, W), bool)
     r = fs // 2
-    for (n, y, xx) in ((0, 2, 5), (0, 6, 1), (1, 4, 4)):
+    for (n, y, xx) in ((0, 2, 5), (0, 6, 1), (1, 4, 4), (1, 1, 6)):
         touched[n, max(0, y - r):y + r + 1, max(0, xx - r):xx + r + 1] = True
+    seen = set()
     for n in range(N):
         g, ref = got[:, n], refs[n]
         t = np.broadcast_to(touched[n], g.shape)
-        assert not np.isfinite(ref[t]).any() and not np.isfinite(g[t]).any(), "an output over a non-finite input must be non-finite in both"
+        assert not np.isfinite(ref[t]).any(), "test set-up: every touched output is non-finite in the reference"
         assert np.isfinite(g[~t]).all(), "a non-finite value leaked into an output whose window does not hold it"
+        assert np.array_equal(np.isnan(g), np.isnan(ref)), "%s frame %d: NaN pattern differs from the reference's at %r" % (name, n, np.argwhere(np.isnan(g) != np.isnan(ref))[:6].tolist())
+        inf = np.isinf(ref)
+        assert np.array_equal(g[inf], ref[inf]), "%s frame %d: +-Inf outputs differ from the reference's" % (name, n)
+        seen |= {"nan"} if np.isnan(ref).any() else set()
+        seen |= {"+inf"} if (ref[inf] > 0).any() else set()
+        seen |= {"-inf"} if (ref[inf] < 0).any() else set()
         close(np.where(t, 0, g), np.where(t, 0, ref), "%s frame %d, finite outputs" % (name, n))
+    assert seen == {"nan", "+inf", "-inf"}, seen
+
+
+@pytest.mark.parametrize("shape", [(16, 96, 16, 1, 2, 40, 40, True), (16, 96, 24, 2, 2, 40, 40, False), (24, 136, 24, 1, 2, 20, 20, True), (48, 224, 48, 1, 2, 10, 10, True),
+                                   (8, 48, 16, 1, 2, 40, 40, False)])
+def test_fused_block_inf_input(env, shape):
+    """the fused expand -> depthwise -> project block (k_irbw / k_irbw2, expand GEMM as split-bf16 products for 16 / 24 / 48 input channels) with a +Inf and a -Inf
+    among its inputs, against the oracle's three groupconv calls + shortcut: the same outputs are +Inf, -Inf and NaN, everything outside the two 3x3
+    neighbourhoods is untouched (round 6: an Inf input used to become NaN in the expand GEMM)"""
+    capi, torch, orc = env
+    ic, ec, oc, stride, N, H, W, use_res = shape
+    rng = np.random.default_rng(77)
+    x = rng.uniform(-1, 1, (ic * N, H, W)).astype(np.float32)
+    xf = x.reshape(ic, N, H, W)
+    xf[1, 0, 5, 4] = np.inf
+    xf[ic - 1, 1, H - 1, W - 2] = -np.inf
+    f1, fd, f2 = make_filter(rng, ec, ic), make_filter(rng, ec, 9), make_filter(rng, oc, ec)
+    f1[0, :ic] = np.round(f1[0, :ic] * 32) / 32                  # bf16 numbers (two zero parts)
+    f1[1, 1] = 0.0                                               # a zero weight on the +Inf channel
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = rng.uniform(-1, 1, (oc * N, OH, OW)).astype(np.float32)
+    t = [torch.from_numpy(a).cuda() for a in (x, f1, fd, f2, res)]
+    out = torch.full((oc * N, OH, OW), float("nan"), device="cuda")
+    capi.irb_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr() if use_res else None, out.data_ptr(), N, W, H, ic, ec, oc, stride)
+    torch.cuda.synchronize()
+    gf, rf = out.cpu().numpy().reshape(oc, N, OH, OW), res.reshape(oc, N, OH, OW)
+    kinds = set()
+    for n in range(N):
+        o1 = orc.groupconv(np.ascontiguousarray(xf[:, n]), f1, 1, 0, 1, 1, 2)
+        o2 = orc.groupconv(o1, fd, ec, 1, stride, 3, 2)
+        o3 = orc.groupconv(o2, f2, 1, 0, 1, 1, 0)
+        if use_res:
+            o3 = orc.shortcut(o3, np.ascontiguousarray(rf[:, n]), 0)
+        g = gf[:, n]
+        assert np.array_equal(np.isnan(g), np.isnan(o3)), "frame %d: NaN pattern differs at %r" % (n, np.argwhere(np.isnan(g) != np.isnan(o3))[:6].tolist())
+        inf = np.isinf(o3)
+        assert np.array_equal(g[inf], o3[inf]), "frame %d: +-Inf outputs differ" % n
+        fin = np.isfinite(o3)
+        assert (~fin).any() and fin.any()
+        close(np.where(fin, g, 0), np.where(fin, o3, 0), "frame %d, finite outputs" % n)
 
 
 # ---------------------------------------------------------------------------------------------------------------- plan freeze (ADVICE r04, medium)

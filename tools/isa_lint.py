@@ -26,7 +26,7 @@ KNOWN_FORMS = {
     'v_pk_add_f32 vc op_sel_hi:[1,0]': 3,
     'v_pk_add_f32 vs neg_hi:[0,1] neg_lo:[0,1]': 69,
     'v_pk_add_f32 vs neg_hi:[0,1] neg_lo:[0,1] op_sel_hi:[1,0]': 51,
-    'v_pk_add_f32 vv neg_hi:[0,1] neg_lo:[0,1]': 7,
+    'v_pk_add_f32 vv neg_hi:[0,1] neg_lo:[0,1]': 43,      # round 6: the wave-level Inf test (x3_wave_has_inf) lets hipcc pack the subtractions of the fused blocks' split; soaked (tests/test_gpu_round5.py)
     'v_pk_fma_f32 vsc op_sel_hi:[1,1,0]': 40,
     'v_pk_fma_f32 vvc op_sel:[0,1,0] op_sel_hi:[1,1,0]': 8,
     'v_pk_fma_f32 vvc op_sel:[1,0,0] op_sel_hi:[1,1,0]': 72,
