@@ -919,6 +919,15 @@ def main():
                              "mfma_f32_frac": round(model_flops / MS / per_gpu_s / 1e12 / FP32_MFMA_PEAK_TF, 4),
                              "batch": B},
         }
+        # measured HBM traffic of one forward: a cited constant from the PMC passes of tools/net_traffic.sh (one chain, batch 64, u8 frames), not collected by this run
+        try:
+            nt = json.load(open(os.path.join(ROOT, "profiles", "r06_net_traffic.json")))
+            if args.input == "u8" and B == 64:
+                out["roofline_net"].update({"traffic": nt["hbm_bytes_per_forward"], "traffic_over_fused_model": nt["traffic_over_fused_model"],
+                                            "traffic_source": "profiles/r06_net_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/net_traffic.sh over the %d launches of one 64-frame forward, "
+                                                              "single chain, calibrated on a bare copy; a cited constant, not collected by this run)" % nt["launches_per_forward"]})
+        except (OSError, KeyError, ValueError):
+            pass
         if J["reps"]:
             rv = [G * args.steps / t for t in J["reps"]]
             srt = sorted(rv)

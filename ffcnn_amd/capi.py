@@ -63,7 +63,7 @@ EXPORTS = ["net_load", "net_free", "net_input", "net_forward", "net_dump", "net_
            "ffgpu_exec_kernel_count", "ffgpu_exec_work_model", "ffgpu_exec_set_scale", "ffgpu_exec_forward_dev", "ffgpu_exec_forward_host",
            "ffgpu_exec_forward_bgr_dev", "ffgpu_exec_dets_dev", "ffgpu_exec_dets_host", "ffgpu_exec_set_ring", "ffgpu_exec_set_ring_strided", "ffgpu_exec_read_dets", "ffgpu_exec_read_layer", "ffgpu_exec_hash_layers",
            "ffgpu_exec_read_boxes", "ffgpu_exec_cand_capacity", "ffgpu_exec_graph_captures",
-           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_dwpw_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records", "ffgpu_unpack_records",
+           "ffgpu_exec_profile", "ffgpu_exec_profile_steps", "ffgpu_exec_step_model", "ffgpu_groupconv_dev", "ffgpu_groupconv_kernel_name", "ffgpu_groupconv_time_dev", "ffgpu_irb_dev", "ffgpu_dwpw_dev", "ffgpu_packed_records_bytes", "ffgpu_pack_records", "ffgpu_unpack_records",
            "ffgpu_shard_range", "ffgpu_node_create", "ffgpu_node_destroy", "ffgpu_node_ndev", "ffgpu_node_shard", "ffgpu_node_set_scale",
            "ffgpu_node_input_dev", "ffgpu_node_input_slot_dev", "ffgpu_node_depth", "ffgpu_node_rccl_ranks", "ffgpu_node_forward", "ffgpu_node_forward_host",
            "ffgpu_node_submit", "ffgpu_node_wait", "ffgpu_node_run"]
@@ -135,6 +135,7 @@ def lib():
     L.ffgpu_exec_hash_layers.argtypes = [vp, vp, i]
     L.ffgpu_exec_profile.argtypes = [vp, vp, f32p]
     L.ffgpu_exec_profile_steps.argtypes = [vp, vp, C.POINTER(i), f32p, i]
+    L.ffgpu_exec_step_model.argtypes = [vp, C.POINTER(i), C.POINTER(C.c_double), i]
     L.ffgpu_groupconv_dev.argtypes = [vp, vp, vp] + [i] * 15 + [vp]
     L.ffgpu_groupconv_kernel_name.restype = C.c_char_p
     L.ffgpu_groupconv_kernel_name.argtypes = [i] * 10
@@ -454,6 +455,13 @@ class Executor:
         lay, us = (C.c_int * cap)(), (C.c_float * cap)()
         n = _check(lib().ffgpu_exec_profile_steps(self.h, dev_ptr, lay, us, cap), "ffgpu_exec_profile_steps")
         return [(lay[k], us[k]) for k in range(n)]
+
+    def step_model(self):
+        """[(layer, model HBM bytes)] per step of the plan (ffgpu_exec_step_model)"""
+        cap = 512
+        lay, by = (C.c_int * cap)(), (C.c_double * cap)()
+        n = _check(lib().ffgpu_exec_step_model(self.h, lay, by, cap), "ffgpu_exec_step_model")
+        return [(lay[k], by[k]) for k in range(n)]
 
     def profile(self, dev_ptr):
         us = (C.c_float * 8)()

@@ -1036,6 +1036,41 @@ extern "C" int ffgpu_exec_kernel_count(const ffgpu_exec *ex) { return ex ? ex->k
 // output, residual, filter rows; nothing for the tensors a fused launch keeps on chip), summed over the launch list; and
 // 2 x multiply-adds of every conv layer of the net (fused or not).  bench.py prices the measured time per batch against
 // these two numbers (HBM peak, fp32 matrix peak).
+// what one step of the plan must move between HBM and the chip, as a model: its input tensor(s) + output tensor + filter rows, each once
+static double step_model_bytes(const ffgpu_exec *ex, const Step &st)
+{
+    const double N = ex->N;
+    auto rows = [](const ConvDesc &d) { return (double)d.oc * (conv_k4(d) + 4); };
+    switch (st.kind) {
+    case S_CONV: { const ConvDesc &d = st.conv;
+        return 4.0 * (N * d.ic * d.ih * d.iw + N * d.oc * d.oh * d.ow * (d.residual ? 2 : 1) + rows(d)); }
+    case S_IRB: { const IrbDesc &d = st.irb;
+        return 4.0 * (N * d.ic * d.H * d.W + N * d.oc * d.OH * d.OW * (d.residual ? 2 : 1) + (double)d.ec * (d.ic + 4 + 16) + (double)d.oc * (d.ec + 4)); }
+    case S_DWPW: { const ConvDesc &a = st.conv, &b = st.conv2;
+        return 4.0 * (N * a.ic * a.ih * a.iw + N * b.oc * b.oh * b.ow + rows(a) + rows(b)); }
+    case S_FRONT: { const ConvDesc &c = st.conv; const IrbDesc &d = st.irb;
+        return 4.0 * (N * c.ic * c.ih * c.iw + N * d.oc * d.OH * d.OW + rows(c)); }
+    case S_POOL: { const int np = 1 + (st.fs2[0] != 0) + (st.fs2[1] != 0);
+        return 4.0 * N * st.c * ((double)st.w * st.h + (double)np * (st.w / st.stride) * (st.h / st.stride)); }
+    case S_UPSAMPLE: return 4.0 * N * st.c * (double)st.w * st.h * (1 + st.stride * st.stride);
+    case S_ADD: return 4.0 * 3 * st.n;
+    case S_COPY: return 4.0 * 2 * st.n;
+    case S_TOCNHW: return 4.0 * 2 * N * st.c * (double)st.w * st.h;
+    case S_YOLO: return 4.0 * N * 3 * (5 + st.head.classes) * (double)st.head.w * st.head.h;
+    default: return 0.0;
+    }
+}
+
+/* the same model step by step (tools/net_traffic.py sets the counters of a rocprofv3 --pmc pass beside it): layer_of[i] / hbm_bytes[i] of step i */
+extern "C" int ffgpu_exec_step_model(const ffgpu_exec *ex, int *layer_of, double *hbm_bytes, int cap)
+{
+    if (!ex || !ex->net || !layer_of || !hbm_bytes) { ffgpu_set_error("step_model: bad argument"); return -1; }
+    if (ex->child[0]) { ffgpu_set_error("step_model: not available on a split executor"); return -1; }
+    const int n = (int)std::min<size_t>(ex->steps.size(), (size_t)(cap > 0 ? cap : 0));
+    for (int i = 0; i < n; i++) { layer_of[i] = ex->steps[i].layer; hbm_bytes[i] = step_model_bytes(ex, ex->steps[i]); }
+    return n;
+}
+
 extern "C" int ffgpu_exec_work_model(const ffgpu_exec *ex, double *hbm_bytes, double *flops)
 {
     if (!ex || !ex->net) { ffgpu_set_error("work_model: bad executor"); return -1; }
@@ -1048,27 +1083,7 @@ extern "C" int ffgpu_exec_work_model(const ffgpu_exec *ex, double *hbm_bytes, do
         }
     } else {
         const double N = ex->N;
-        auto rows = [](const ConvDesc &d) { return (double)d.oc * (conv_k4(d) + 4); };
-        for (const Step &st : ex->steps) {
-            switch (st.kind) {
-            case S_CONV: { const ConvDesc &d = st.conv;
-                by += 4.0 * (N * d.ic * d.ih * d.iw + N * d.oc * d.oh * d.ow * (d.residual ? 2 : 1) + rows(d)); break; }
-            case S_IRB: { const IrbDesc &d = st.irb;
-                by += 4.0 * (N * d.ic * d.H * d.W + N * d.oc * d.OH * d.OW * (d.residual ? 2 : 1) + (double)d.ec * (d.ic + 4 + 16) + (double)d.oc * (d.ec + 4)); break; }
-            case S_DWPW: { const ConvDesc &a = st.conv, &b = st.conv2;
-                by += 4.0 * (N * a.ic * a.ih * a.iw + N * b.oc * b.oh * b.ow + rows(a) + rows(b)); break; }
-            case S_FRONT: { const ConvDesc &c = st.conv; const IrbDesc &d = st.irb;
-                by += 4.0 * (N * c.ic * c.ih * c.iw + N * d.oc * d.OH * d.OW + rows(c)); break; }
-            case S_POOL: { const int np = 1 + (st.fs2[0] != 0) + (st.fs2[1] != 0);
-                by += 4.0 * N * st.c * ((double)st.w * st.h + (double)np * (st.w / st.stride) * (st.h / st.stride)); break; }
-            case S_UPSAMPLE: by += 4.0 * N * st.c * (double)st.w * st.h * (1 + st.stride * st.stride); break;
-            case S_ADD: by += 4.0 * 3 * st.n; break;
-            case S_COPY: by += 4.0 * 2 * st.n; break;
-            case S_TOCNHW: by += 4.0 * 2 * N * st.c * (double)st.w * st.h; break;
-            case S_YOLO: by += 4.0 * N * 3 * (5 + st.head.classes) * (double)st.head.w * st.head.h; break;
-            default: break;
-            }
-        }
+        for (const Step &st : ex->steps) by += step_model_bytes(ex, st);
         const LAYER *ll = ex->net->layer_list;
         for (int i = 0; i < ex->net->layer_num; i++)
             if (ll[i].type == LAYER_TYPE_CONV)

@@ -163,6 +163,9 @@ int ffgpu_exec_profile(ffgpu_exec *ex, const float *d_frames, float us_by_kind[L
  * reference layer index it implements (-1: executor bookkeeping), us[i] its
  * device time.  Returns the number of steps (<= cap) or a negative error. */
 int ffgpu_exec_profile_steps(ffgpu_exec *ex, const float *d_frames, int *layer_of, float *us, int cap);
+/* The HBM byte model of ffgpu_exec_work_model step by step: hbm_bytes[i] = what step i must move (its input and
+ * output tensors and filter rows, each once), layer_of[i] as above.  Returns the number of steps (<= cap). */
+int ffgpu_exec_step_model(const ffgpu_exec *ex, int *layer_of, double *hbm_bytes, int cap);
 
 /* ---- all GPUs of one node from one C process (counterpart of calling net_forward once per frame) ------
  * A batch of `global_batch` independent frames is cut into contiguous shards, one per device (ffgpu_shard_range); every
