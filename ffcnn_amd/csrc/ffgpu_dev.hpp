@@ -38,7 +38,7 @@ struct ConvDesc {
     int   nsplit;         // implicit-GEMM split-K factor frozen at plan time (ffgpu_conv_plan); 0 = decided at launch (single-layer calls)
     int   kernel;         // FFGPU_K_* frozen at plan time (ffgpu_conv_plan): ffgpu_launch_conv(AUTO), the pack size and the pack kernel all follow it,
                           // so a later change of the FFGPU_* tuning environment cannot pair one kernel with another kernel's weight image; 0 = pick at launch
-    int   x3_mt;          // k_conv_x3's MT (16-row blocks per wave: the layout of its packed image) frozen with the plan; 0 = decided at launch
+    int   x3_mt;          // k_conv_x3's MT (16-row blocks per wave) / k_pw_x3t's RB (32-row blocks per wave): the layout of the packed image, frozen with the plan; 0 = decided at launch
 };
 // internal bit of ConvDesc::flags (never part of the public flag set): the step reads the executor's BATCH INPUT (frame-major, possibly through the
 // parameter block) -- kernels that cannot read through ConvDesc::in_ind are not picked for it, so the one-graph-for-every-input property survives
@@ -54,10 +54,12 @@ struct IrbDesc {
     int act1, actd, act2, res_act;
     const float *pk;          // packed constants (ffgpu_irb_pack_floats floats, filled by ffgpu_irb_pack)
     int flags;                // FFGPU_CONCURRENT: tile splits chosen for several chains in flight
+    int half;                 // k_irbw's "half last group" form frozen with the plan (ffgpu_irb_plan): 0 = decided at every call (single-block calls), 1 = off, 2 = on
 };
 bool   ffgpu_irb_supported(const IrbDesc &d);
 bool   ffgpu_irb_is_thin(const IrbDesc &d);      // 8 expanded channels: streaming VALU kernel instead of the MFMA/LDS one
 size_t ffgpu_irb_pack_floats(const IrbDesc &d);
+void   ffgpu_irb_plan(IrbDesc &d);                     // freezes what the packed image's layout depends on (FFGPU_IRBW_HALF is read once, here)
 int    ffgpu_irb_pack(const IrbDesc &d, float *pk, hipStream_t s);
 int    ffgpu_launch_irb(const IrbDesc &d, hipStream_t s);
 bool   ffgpu_front_ok(const ConvDesc &c, const IrbDesc &d);      // first layer (3x3 s2, 3 -> 8) + thin block as one streaming kernel

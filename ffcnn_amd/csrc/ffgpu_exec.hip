@@ -596,7 +596,7 @@ static int plan(ffgpu_exec *ex)
     {   // constants of the fused blocks, packed once into their LDS image
         size_t tot = 0;
         for (Step &st : S) {
-            if (st.kind == S_IRB) tot += ffgpu_irb_pack_floats(st.irb);
+            if (st.kind == S_IRB) { ffgpu_irb_plan(st.irb); tot += ffgpu_irb_pack_floats(st.irb); }
             if (st.kind == S_CONV) {                              // kernel choice, split-K and k_conv_x3's MT frozen with the plan
                 if (st.in_is_input) st.conv.flags |= FFGPU_F_BATCH_INPUT;
                 ffgpu_conv_plan(st.conv);

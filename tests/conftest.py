@@ -51,7 +51,7 @@ def test_image(orc):
 # create and destroy hundreds of executors come last and run in a child interpreter: a runtime abort() inside one of them is then one
 # red test with its stderr attached, not the end of the session.
 _FILE_ORDER = ["test_gpu_parity", "test_gpu_round2", "test_gpu_round3", "test_gpu_round4", "test_gpu_round5", "test_gpu_kernels", "test_gpu_bench_modes", "test_gpu_geometries",
-               "test_gpu_cfg_styles", "test_gpu_load_failures", "test_gpu_fuzz_input", "test_gpu_fuzz_nets", "test_gpu_fuzz",
+               "test_gpu_cfg_styles", "test_gpu_load_failures", "test_gpu_hazard_controls", "test_gpu_fuzz_input", "test_gpu_fuzz_nets", "test_gpu_fuzz",
                "test_gpu_node_rccl", "test_gpu_fuzz_api"]
 # the BASELINE.json configs and the golden fixtures, in this order, before everything else that needs the GPU
 _FRONT = ["test_dw_config1_full_batch_sampled", "test_pw_config2_against_oracle", "test_net_api_single_frame", "test_cli_geometry_640x448",
