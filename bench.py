@@ -252,34 +252,12 @@ def pw_roofline(torch, capi, stream):
                                  warmup=4, iters=50, stream=stream.cuda_stream)
     flops = 2.0 * oc * ic * N * H * W
     tfs = flops / (us * 1e-6) / 1e12
-    # beside it: the fp32-MFMA kernel of rounds 2-3 on the same tensors (k_pw_gemm32: v_mfma_f32_32x32x2_f32, the kernel AUTO picked until round 4)
-    f32k = None
-    try:
-        us32 = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2,
-                                       variant=capi.FFGPU.K_PW_GEMM, warmup=4, iters=30, stream=stream.cuda_stream)
-        f32k = {"kernel": "pw_gemm", "us_per_launch": round(us32, 2), "achieved": round(flops / us32 / 1e6, 2), "unit": "TFLOP/s", "frac": round(flops / us32 / 1e6 / FP32_MFMA_PEAK_TF, 4)}
-    except RuntimeError:
-        pass
-    # beside it (NOT the product default, never used by the net's timed steps): the opt-in bf16-input variant of the same layer
-    # (FFGPU_BF16_PW; its own tolerance in tests/test_gpu_kernels.py::test_pw_bf16) -- on the bf16 matrix cores the layer is
-    # HBM-bound: 315 MB of fp32 input + output per launch
-    bf = None
-    try:
-        us_bf = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2, flags=capi.FFGPU.BF16_PW,
-                                        variant=capi.FFGPU.K_AUTO, warmup=4, iters=30, stream=stream.cuda_stream)
-        by = 4.0 * (ic + oc) * N * H * W
-        bf = {"kernel": "pw_bf16", "us_per_launch": round(us_bf, 2), "bound": "hbm", "achieved": round(by / us_bf / 1e3, 1), "peak": HBM_PEAK_GBS,
-              "unit": "GB/s", "frac": round(by / us_bf / 1e3 / HBM_PEAK_GBS, 4), "speedup_vs_f32": round(us / us_bf, 2),
-              "note": "opt-in reduced precision (bf16 inputs, fp32 accumulation); tolerance 2^-7 scale' sum|w x| per output"}
-    except RuntimeError:
-        pass
-    kname = capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc)
-    split = kname in ("pw_x3", "pw_x3s", "pw_x3t")
-    # beside it: the MFMA-only floor of this launch on this box -- the launch's 4 915 200 v_mfma_f32_32x32x16_bf16 in k_pw_x3t's chunk pattern
+    # beside it, RIGHT BEHIND the kernel's own launches and in front of the two cooler variants below (80 launches of pure bf16 MFMA leave the chip at its lowest
+    # clock: measured last, they sat directly in front of the net's timed region and cost its first 20 steps 2-5 %): the MFMA-only floor of this launch on this box -- the launch's 4 915 200 v_mfma_f32_32x32x16_bf16 in k_pw_x3t's chunk pattern
     # on operands split from the same distributions and NOTHING else (lab kernel in libffcnn_hip_diag.so, wrong results by construction; tools/mfma_floor.py):
     # the time the power limit grants the arithmetic alone.  `frac` stays priced against the spec peak; `frac_of_floor` says how much of the gap is the chip's.
     floor = None
-    if kname == "pw_x3t":
+    if capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc) == "pw_x3t":
         try:
             import numpy as np
             D = capi.diag()
@@ -309,6 +287,29 @@ def pw_roofline(torch, capi, stream):
                                  "no loads, no split, no LDS, no stores (ffgpu_mfma_floor, lab library); power-limited clock" % n_mfma}
         except (OSError, AttributeError, RuntimeError):
             floor = None
+    # beside it: the fp32-MFMA kernel of rounds 2-3 on the same tensors (k_pw_gemm32: v_mfma_f32_32x32x2_f32, the kernel AUTO picked until round 4)
+    f32k = None
+    try:
+        us32 = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2,
+                                       variant=capi.FFGPU.K_PW_GEMM, warmup=4, iters=30, stream=stream.cuda_stream)
+        f32k = {"kernel": "pw_gemm", "us_per_launch": round(us32, 2), "achieved": round(flops / us32 / 1e6, 2), "unit": "TFLOP/s", "frac": round(flops / us32 / 1e6 / FP32_MFMA_PEAK_TF, 4)}
+    except RuntimeError:
+        pass
+    # beside it (NOT the product default, never used by the net's timed steps): the opt-in bf16-input variant of the same layer
+    # (FFGPU_BF16_PW; its own tolerance in tests/test_gpu_kernels.py::test_pw_bf16) -- on the bf16 matrix cores the layer is
+    # HBM-bound: 315 MB of fp32 input + output per launch
+    bf = None
+    try:
+        us_bf = capi.groupconv_time_dev(x.data_ptr(), filt.data_ptr(), y.data_ptr(), N, W, H, ic, 1, 0, 1, 1, oc, act=2, flags=capi.FFGPU.BF16_PW,
+                                        variant=capi.FFGPU.K_AUTO, warmup=4, iters=30, stream=stream.cuda_stream)
+        by = 4.0 * (ic + oc) * N * H * W
+        bf = {"kernel": "pw_bf16", "us_per_launch": round(us_bf, 2), "bound": "hbm", "achieved": round(by / us_bf / 1e3, 1), "peak": HBM_PEAK_GBS,
+              "unit": "GB/s", "frac": round(by / us_bf / 1e3 / HBM_PEAK_GBS, 4), "speedup_vs_f32": round(us / us_bf, 2),
+              "note": "opt-in reduced precision (bf16 inputs, fp32 accumulation); tolerance 2^-7 scale' sum|w x| per output"}
+    except RuntimeError:
+        pass
+    kname = capi.kernel_name(N, W, H, ic, 1, 0, 1, 1, oc)
+    split = kname in ("pw_x3", "pw_x3s", "pw_x3t")
     note = None
     if split:
         note = ("fp32-equivalent results from split operands: every fp32 value = three exact bf16 parts, six partial products per multiply-add on the bf16 "
